@@ -1,0 +1,184 @@
+/*
+ * rays_hip.h -- C ABI of the MI355X-native RAYS ray-trajectory integrator (librays_hip.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of ORNL-Fusion/RAYS:
+ *
+ *     call trace_rays            RAYS_project/RAYS_code/RAYS.f90:13
+ *                                RAYS_project/RAYS_lib/ray_tracing.f90:1-290
+ *
+ * i.e. the per-ray ODE march  ode_solver(RK4_ode | SG_ode) -> eqn_ray ->
+ * equilibrium(slab | solovev) + deriv_cold | deriv_num -> check_save, for all rays of a fan.
+ * The reference has no process/device boundary (module state in, ray_results_m arrays out);
+ * the binding a RAYS maintainer adds is the iso_c_binding interface in fortran/rays_hip_m.f90
+ * plus the replacement trace_rays in fortran/trace_rays_hip.f90.
+ *
+ * Conventions
+ *   - plain C types only; every array is caller-owned; the library never keeps a host pointer
+ *     after a call returns.
+ *   - return 0 on success; non-zero = HIP failure / bad configuration, message via
+ *     rays_hip_last_error().  A ray that stops is NOT an error: it gets a stop code
+ *     (RAYS_STOP_*), mapped to the reference's ode_stop_flag text by rays_hip_stop_flag_text().
+ *   - all reals are IEEE binary64 (reference rkind = selected_real_kind(15,307),
+ *     constants_m.f90:14), counters are 32-bit.
+ *   - array layouts are exactly the reference's Fortran arrays (ray_results_m.f90:44-58):
+ *       ray_vec (nv, nstep_max+1, nray)  column-major == C [nray][nstep_max+1][nv]
+ *       residual(nstep_max+1, nray)      column-major == C [nray][nstep_max+1]
+ *       rvec0(3,nray), rindex_vec0(3,nray)             == C [nray][3]   (ray_init_m.f90:47-53)
+ *     Entries past npoints(iray) are zero, as after initialize_ray_results_m (154-164).
+ */
+#ifndef RAYS_HIP_H
+#define RAYS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAYS_ABI_VERSION 1
+#define RAYS_NSPEC0 5 /* species_m.f90:25  nspec0; arrays are dimensioned 0:nspec0 */
+#define RAYS_NS0 (RAYS_NSPEC0 + 1)
+
+/* ---- selectors: integer images of the reference's string switches ----------------------- */
+enum { RAYS_ODE_RK4 = 0, RAYS_ODE_SG = 1 };           /* ode_m.f90:238  'RK4_ODE' | 'SG_ODE'   */
+enum { RAYS_DERIV_COLD = 0, RAYS_DERIV_NUM = 1 };     /* eqn_ray.f90:106 'cold' | 'numerical'  */
+enum { RAYS_PARAM_ARCL = 0, RAYS_PARAM_TIME = 1 };    /* eqn_ray.f90:148 'arcl' | 'time'       */
+enum { RAYS_EQ_SLAB = 0, RAYS_EQ_SOLOVEV = 1 };       /* equilibrium_m.f90:177                 */
+
+/* slab_eq_m.f90:172-300 profile-model strings */
+enum { RAYS_SLAB_BX_ZERO = 0 };
+enum { RAYS_SLAB_BY_ZERO = 0, RAYS_SLAB_BY_CONSTANT, RAYS_SLAB_BY_TOROID, RAYS_SLAB_BY_LINEAR_SHEAR };
+enum { RAYS_SLAB_BZ_CONSTANT = 0, RAYS_SLAB_BZ_TOROID, RAYS_SLAB_BZ_LINEAR, RAYS_SLAB_BZ_LINEAR_2 };
+enum { RAYS_SLAB_N_CONSTANT = 0, RAYS_SLAB_N_LINEAR, RAYS_SLAB_N_LINEAR_2, RAYS_SLAB_N_PARABOLIC,
+       RAYS_SLAB_N_GAUSSIAN };
+enum { RAYS_SLAB_T_ZERO = 0, RAYS_SLAB_T_CONSTANT, RAYS_SLAB_T_LINEAR, RAYS_SLAB_T_LINEAR_2,
+       RAYS_SLAB_T_PARABOLIC };
+/* solovev_eq_m.f90:208-267 */
+enum { RAYS_SOLOVEV_N_CONSTANT = 0, RAYS_SOLOVEV_N_PARABOLIC };
+enum { RAYS_SOLOVEV_T_ZERO = 0, RAYS_SOLOVEV_T_PARABOLIC = 2 };
+
+/* ---- per-ray stop codes  <->  reference ode_stop_flag strings ---------------------------- */
+enum {
+  RAYS_STOP_NONE = 0,
+  RAYS_STOP_SOUT_GT_SMAX = 1,      /* 'sout > s_max'            ray_tracing.f90:144 */
+  RAYS_STOP_NSTEP_MAX = 2,         /* ' nstep > nstep_max'      ray_tracing.f90:152 (leading blank) */
+  RAYS_STOP_X_OUT_OF_BOUNDS = 10,  /* 'x out_of_bounds'         slab_eq_m.f90:163 */
+  RAYS_STOP_Y_OUT_OF_BOUNDS = 11,  /* 'y out_of_bounds'         slab_eq_m.f90:164 */
+  RAYS_STOP_Z_OUT_OF_BOUNDS = 12,  /* 'z out_of_bounds'         slab_eq_m.f90:165 */
+  RAYS_STOP_NEGATIVE_DENS = 13,    /* 'negative_dens'           slab_eq_m.f90:305, solovev_eq_m.f90:272 */
+  RAYS_STOP_NEGATIVE_TEMP = 14,    /* 'negative_temp'           slab_eq_m.f90:306, solovev_eq_m.f90:273 */
+  RAYS_STOP_R_OUT_OF_BOX = 20,     /* 'R out_of_box'            solovev_eq_m.f90:155 */
+  RAYS_STOP_Z_OUT_OF_BOX = 21,     /* 'z out_of_box'            solovev_eq_m.f90:156 */
+  RAYS_STOP_INFINITE_VG_RHS = 30,  /* 'infinite Vg'             eqn_ray.f90:142 */
+  RAYS_STOP_RAY_STALLED = 31,      /* 'ray stalled'             eqn_ray.f90:168 */
+  RAYS_STOP_DISP_RESIDUAL = 40,    /* 'dispersion_residual'     check_save.f90:70 */
+  RAYS_STOP_INFINITE_VG_CHECK = 41,/* 'infinite_Vg'             check_save.f90:108 */
+  RAYS_STOP_TOTAL_ABSORPTION = 42, /* 'total_absorption'        check_save.f90:123 */
+  RAYS_STOP_ODE_TOTAL_ERROR = 50,  /* 'ODE total error'         SG_ode_m.f90:144 */
+  RAYS_STOP_SG_MAXNUM = 51,        /* 'step number .ge. maxnum' ode_RAYS.f90:538 */
+  RAYS_STOP_SG_STIFF = 52,         /* 'equations stiff'         ode_RAYS.f90:541 */
+  RAYS_STOP_SG_T_EQ_TOUT = 53,     /* 't == tout'               ode_RAYS.f90:433 */
+  RAYS_STOP_SG_NEG_ERR = 54,       /* 'relerr or abserr < 0'    ode_RAYS.f90:439 */
+  RAYS_STOP_SG_EPS_LE_0 = 55       /* 'eps <= 0'                ode_RAYS.f90:447 */
+};
+
+/* ---- slab_eq_m.f90:35-85 namelist /slab_eq_list/ ------------------------------------------ */
+typedef struct rays_slab_params {
+  int32_t bx_prof_model, by_prof_model, bz_prof_model, dens_prof_model;
+  int32_t t_prof_model[RAYS_NS0];
+  int32_t pad_[2];
+  double xmin, xmax, ymin, ymax, zmin, zmax;
+  double rmaj, rmin, x0;
+  double bx0, by0, bz0, LBy_shear_scale, LBz_scale, dBzdx;
+  double Ln_scale, dndx, alphan1, alphan2, n_min;
+  double LT_scale, dtdx;
+  double alphat1[RAYS_NS0], alphat2[RAYS_NS0], T_min[RAYS_NS0];
+} rays_slab_params_t;
+
+/* ---- solovev_eq_m.f90:17-45 namelist /solovev_eq_list/ + derived psiB (:92) --------------- */
+typedef struct rays_solovev_params {
+  int32_t dens_prof_model;
+  int32_t t_prof_model[RAYS_NS0];
+  int32_t pad_[1];
+  double rmaj, kappa, bphi0, iota0, outer_bound;
+  double psiB; /* computed by the host exactly as solovev_eq_m.f90:89-92 */
+  double alphan1, alphan2;
+  double alphat1[RAYS_NS0], alphat2[RAYS_NS0];
+  double box_rmin, box_rmax, box_zmin, box_zmax;
+} rays_solovev_params_t;
+
+/* ---- everything trace_rays reads from module state ----------------------- */
+typedef struct rays_params {
+  int32_t abi_version;  /* RAYS_ABI_VERSION */
+  int32_t nv;           /* ode_m.f90:160-173: 7, +5 with integrate_eq_gradients */
+  int32_t nspec;        /* species_m.f90:27 number of ion species (electrons are species 0) */
+  int32_t nstep_max;    /* ode_m.f90:104 */
+  int32_t ode_solver;   /* RAYS_ODE_* */
+  int32_t ray_deriv;    /* RAYS_DERIV_* */
+  int32_t ray_param;    /* RAYS_PARAM_* */
+  int32_t equilib_model;/* RAYS_EQ_* */
+  int32_t integrate_eq_gradients; /* diagnostics_m.f90:101 */
+  int32_t pad_[3];
+  double ds, s_max;                    /* ode_m.f90:98-101 */
+  double omgrf, k0;                    /* rf_m.f90:18-21 (passed by value: never re-derived) */
+  double clight, eps0;                 /* constants_m.f90:42-44 (single-precision literals!) */
+  double dispersion_resid_limit;       /* rf_m.f90:48 */
+  double rel_err0, abs_err0, SG_error_limit; /* SG_ode_m.f90:26-31 */
+  double qs[RAYS_NS0], ms[RAYS_NS0];   /* species_m.f90:71-72, SI units after init (155-157) */
+  double n0s[RAYS_NS0], t0s[RAYS_NS0]; /* species_m.f90:42-44 */
+  double eta[RAYS_NS0];                /* species_m.f90:73 */
+  rays_slab_params_t slab;
+  rays_solovev_params_t solovev;
+} rays_params_t;
+
+/* ---- library control ----------------------------------------------------------------------- */
+/* Select up to ngpu visible devices for rays_hip_trace (0 = all).  Returns the number in use,
+ * or a negative value on failure.  Optional: rays_hip_trace initialises lazily. */
+int rays_hip_init(int ngpu);
+int rays_hip_finalize(void);
+int rays_hip_device_count(void);
+/* Copies the last error message (NUL-terminated, truncated to len) and returns its length. */
+int rays_hip_last_error(char* buf, int len);
+/* Reference ode_stop_flag text for a stop code (e.g. " nstep > nstep_max"); "" if unknown. */
+const char* rays_hip_stop_flag_text(int stop_code);
+/* Validates a parameter block exactly as the reference's `stop 1` configuration checks would;
+ * 0 if the device path supports it. */
+int rays_hip_check_params(const rays_params_t* p);
+
+/* ---- the hot path, host-pointer form: replaces `call trace_rays` ---------------------------
+ * Blocking.  Shards rays in contiguous blocks over the selected GPUs (the reference's
+ * OpenMP `schedule(static)`, ray_tracing.f90:62), copies each device's contiguous output slab
+ * straight into the caller's arrays.  Optional outputs may be NULL.
+ *   stop_code[nray]          integer image of ray_stop_flag(iray)          (ray_tracing.f90:258)
+ *   end_ray_vec[nray][nv]    v at the last valid step                       (ray_tracing.f90:260)
+ *   end_residuals[nray]      residual(nstep,iray)                           (ray_tracing.f90:255)
+ *   max_residuals[nray]      maxval(abs(residual(1:nstep,iray)))            (ray_tracing.f90:256)
+ *   elapsed_s                wall seconds of the device work incl. copies
+ */
+int rays_hip_trace(const rays_params_t* p, int nray,
+                   const double* rvec0, const double* rindex_vec0,
+                   double* ray_vec, double* residual, int32_t* npoints, int32_t* stop_code,
+                   double* end_ray_vec, double* end_residuals, double* max_residuals,
+                   double* elapsed_s);
+
+/* ---- the hot path, device-pointer form ------------------------------------------------------
+ * All pointers are device memory on the CURRENT HIP device; the launch is asynchronous on
+ * `hip_stream` (a hipStream_t, NULL = default stream).  ray_vec/residual are zero-filled by the
+ * call (hipMemsetAsync on the same stream) unless RAYS_TRACE_NO_ZERO_FILL is set in flags.
+ * Used by the Python host (torch tensors), by bench.py, and by rays_hip_trace itself.
+ */
+enum { RAYS_TRACE_NO_ZERO_FILL = 1 };
+int rays_hip_trace_device(const rays_params_t* p, int nray,
+                          const double* d_rvec0, const double* d_rindex_vec0,
+                          double* d_ray_vec, double* d_residual, int32_t* d_npoints,
+                          int32_t* d_stop_code, double* d_end_ray_vec, double* d_end_residuals,
+                          double* d_max_residuals, void* hip_stream, int flags);
+
+/* Name of the kernel specialisation rays_hip_trace_device would launch for p (for profiling
+ * scripts: matches the rocprofv3 kernel-trace name prefix). */
+const char* rays_hip_kernel_name(const rays_params_t* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYS_HIP_H */

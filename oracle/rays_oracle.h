@@ -1,0 +1,33 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement of the RAYS hot path (see rays_oracle.c).
+ * Shares only the POD parameter block / stop codes with the product header. */
+#ifndef RAYS_ORACLE_H
+#define RAYS_ORACLE_H
+#include "../include/rays_hip.h"
+
+#define RAYS_ORACLE_NV_MAX 12
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int (*rays_oracle_rhs_fn)(void* ctx, const double* v, double* dvds);
+
+int rays_oracle_check_params(const rays_params_t* P);
+
+/* Same argument meaning as rays_hip_trace (include/rays_hip.h); host pointers; nthreads <= 0 =
+ * all OpenMP threads.  nrhs_total (optional) counts eqn_ray calls made by the SG stepper. */
+int rays_oracle_trace(const rays_params_t* P, int nray, const double* rvec0,
+                      const double* rindex_vec0, double* ray_vec, double* residual,
+                      int32_t* npoints, int32_t* stop_code, double* end_ray_vec,
+                      double* end_residuals, double* max_residuals, int nthreads,
+                      long long* nrhs_total);
+
+/* One-state probe of equilibrium / deriv_cold / deriv_num / eqn_ray / check_save.
+ * eq_out needs 28 + 12*(nspec+1) doubles; cold7/num7 = dddx(3) dddk(3) dddw; codes[4]. */
+void rays_oracle_probe(const rays_params_t* P, const double* v, double* eq_out, double* cold7,
+                       double* num7, double* dvds, double* resid, int32_t* codes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,159 @@
+! TEST INFRASTRUCTURE ONLY.
+! Driver written for this repo (not reference code): links against the reference RAYS_lib
+! objects built by oracle/build_ref.sh, runs the reference's own
+!     initialize -> trace_rays      (RAYS_project/RAYS_code/RAYS.f90:10-16)
+! and dumps module state + ray_results_m arrays as one raw little-endian stream file so that
+! golden vectors (tests/golden/) can be cut from it and so the CPU reference path can be timed
+! (omp_get_wtime around trace_rays only; SURVEY.md 8(d)).
+!
+! Controlled by environment variables (the reference allows at most one argv = namelist file):
+!   RAYS_DUMP_FILE   output path (default ref_dump.bin); 'none' = no dump, timing only
+!   RAYS_DUMP_PROBE  stride (in recorded points) for per-state probes of equilibrium,
+!                    deriv_cold, deriv_num, eqn_ray, check_save; 0/unset = no probes
+!   RAYS_DUMP_REPS   repeat trace_rays this many times for timing (default 1)
+!
+! When linked as oracle/_ref/rays_hip_dropin the same driver runs with trace_rays replaced by
+! fortran/trace_rays_hip.f90 (the C-ABI drop-in), so both binaries write the same format.
+program ref_dump_driver
+    use constants_m, only : rkind, clight, eps0
+    use species_m, only : nspec, qs, ms, n0s, t0s, eta
+    use rf_m, only : omgrf, k0, dispersion_resid_limit
+    use ode_m, only : nv, ds, s_max, nstep_max, ode_stop
+    use ray_init_m, only : nray, rvec0, rindex_vec0
+    use ray_results_m, only : ray_vec, residual, npoints, ray_stop_flag, end_ray_vec
+    use equilibrium_m, only : equilibrium, eq_point, equilib_model
+    use solovev_eq_m, only : rmaj, kappa, bphi0, iota0, outer_bound, psiB
+    use omp_lib
+    implicit none
+
+    logical :: read_input = .true.
+    character(len=256) :: fname, sval
+    integer :: u, stat, probe_stride, reps, irep, iray, j, nprobe, is
+    real(kind=rkind) :: t0, t1, wall, resid, s
+    real(kind=rkind), allocatable :: v(:), dvds(:)
+    real(kind=rkind) :: dddx(3), dddk(3), dddw, ndx(3), ndk(3), ndw, nvec(3)
+    type(eq_point) :: eq
+    type(ode_stop) :: rs
+    integer(kind=8) :: total_steps
+
+    interface
+       subroutine deriv_cold(eq, nvec, dddx, dddk, dddw)
+          use constants_m, only : rkind
+          use equilibrium_m, only : eq_point
+          type(eq_point), intent(in) :: eq
+          real(KIND=rkind), intent(in) :: nvec(3)
+          real(KIND=rkind), intent(out) :: dddx(3), dddk(3), dddw
+       end subroutine deriv_cold
+       subroutine deriv_num(eq, v, dddx, dddk, dddw)
+          use constants_m, only : rkind
+          use equilibrium_m, only : eq_point
+          use ode_m, only : nv
+          type(eq_point), intent(in) :: eq
+          real(KIND=rkind), intent(in) :: v(nv)
+          real(KIND=rkind), intent(out) :: dddx(3), dddk(3), dddw
+       end subroutine deriv_num
+       subroutine eqn_ray(s, v, dvds, ray_stop)
+          use constants_m, only : rkind
+          use ode_m, only : nv, ode_stop
+          real(KIND=rkind), intent(in) :: s
+          real(KIND=rkind), intent(in) :: v(nv)
+          real(KIND=rkind), intent(out) :: dvds(nv)
+          type(ode_stop) :: ray_stop
+       end subroutine eqn_ray
+       subroutine check_save(s, nv, v, resid, ray_stop)
+          use constants_m, only : rkind
+          use ode_m, only : ode_stop
+          real(KIND=rkind), intent(in) :: s
+          integer, intent(in) :: nv
+          real(KIND=rkind), intent(in) :: v(nv)
+          real(KIND=rkind), intent(out) :: resid
+          type(ode_stop) :: ray_stop
+       end subroutine check_save
+    end interface
+
+    fname = 'ref_dump.bin'
+    call get_environment_variable('RAYS_DUMP_FILE', sval, status=stat)
+    if (stat == 0 .and. len_trim(sval) > 0) fname = sval
+    probe_stride = 0
+    call get_environment_variable('RAYS_DUMP_PROBE', sval, status=stat)
+    if (stat == 0 .and. len_trim(sval) > 0) read(sval, *) probe_stride
+    reps = 1
+    call get_environment_variable('RAYS_DUMP_REPS', sval, status=stat)
+    if (stat == 0 .and. len_trim(sval) > 0) read(sval, *) reps
+
+    call initialize(read_input)
+
+    wall = huge(wall)
+    do irep = 1, reps
+       if (irep > 1) then      ! results arrays are expected zero-filled (ray_results_m.f90:154-164)
+          ray_vec = 0. ; residual = 0. ; npoints = 0 ; end_ray_vec = 0. ; ray_stop_flag = ''
+       end if
+       t0 = omp_get_wtime()
+       call trace_rays
+       t1 = omp_get_wtime()
+       wall = min(wall, t1 - t0)
+    end do
+
+    total_steps = 0
+    do iray = 1, nray
+       total_steps = total_steps + max(npoints(iray) - 1, 0)
+    end do
+    write(*,'(a,i0)')     'RAYS_REF nray = ', nray
+    write(*,'(a,i0)')     'RAYS_REF total_steps = ', total_steps
+    write(*,'(a,es16.8)') 'RAYS_REF trace_wall_s = ', wall
+    write(*,'(a,i0)')     'RAYS_REF threads = ', omp_get_max_threads()
+    write(*,'(a,es16.8)') 'RAYS_REF steps_per_s = ', real(total_steps, rkind)/wall
+
+    if (trim(fname) == 'none') stop
+
+    open(newunit=u, file=trim(fname), access='stream', form='unformatted', status='replace')
+    write(u) int(z'52415953'), 2, nray, nv, nstep_max, nspec, probe_stride, 0
+    write(u) omgrf, k0, clight, eps0, ds, s_max, dispersion_resid_limit, wall
+    write(u) qs(0:5), ms(0:5), n0s(0:5), t0s(0:5), eta(0:5)
+    write(u) rmaj, kappa, bphi0, iota0, outer_bound, psiB
+    write(u) rvec0(1:3,1:nray), rindex_vec0(1:3,1:nray)
+    write(u) npoints(1:nray)
+    write(u) ray_stop_flag(1:nray)
+    write(u) ray_vec
+    write(u) residual
+    write(u) end_ray_vec
+
+    ! ---- optional per-state probes of the RHS pieces (unit parity for the restatement) ----
+    if (probe_stride > 0) then
+       allocate(v(nv), dvds(nv))
+       nprobe = 0
+       do iray = 1, nray
+          do j = 1, npoints(iray), probe_stride
+             nprobe = nprobe + 1
+          end do
+       end do
+       write(u) nprobe
+       do iray = 1, nray
+          do j = 1, npoints(iray), probe_stride
+             v = ray_vec(:, j, iray)
+             s = (j-1)*ds
+             call equilibrium(v(1:3), eq)
+             nvec = v(4:6)/k0
+             call deriv_cold(eq, nvec, dddx, dddk, dddw)
+             call deriv_num(eq, v, ndx, ndk, ndw)
+             rs%stop_ode = .false. ; rs%ode_stop_flag = ''
+             dvds = 0.
+             call eqn_ray(s, v, dvds, rs)
+             rs%stop_ode = .false. ; rs%ode_stop_flag = ''
+             call check_save(s, nv, v, resid, rs)
+             write(u) iray, j
+             write(u) v
+             write(u) eq%bvec, eq%bmag, eq%gradbmag, eq%bunit, eq%gradbunit, eq%gradbtensor
+             do is = 0, nspec
+                write(u) eq%ns(is), eq%gradns(:,is), eq%ts(is), eq%gradts(:,is), &
+                       & eq%omgc(is), eq%omgp2(is), eq%alpha(is), eq%gamma(is)
+             end do
+             write(u) dddx, dddk, dddw
+             write(u) ndx, ndk, ndw
+             write(u) dvds
+             write(u) resid
+          end do
+       end do
+    end if
+    close(u)
+end program ref_dump_driver

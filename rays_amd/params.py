@@ -1,0 +1,280 @@
+"""Host-side image of the module state `trace_rays` reads.
+
+Mirrors, value for value, what the reference's `initialize` leaves in
+constants_m / species_m / rf_m / ode_m / SG_ode_m / slab_eq_m / solovev_eq_m
+(RAYS_project/RAYS_lib/intialize.f90:50-75) and packs it into the POD ``rays_params_t`` of
+include/rays_hip.h.  The reference assigns *single-precision literals* to doubles
+(constants_m.f90:39-48); those are reproduced through ``np.float32`` so every constant handed to
+the device is bit-identical to the Fortran host's.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Dict
+
+import numpy as np
+
+NS0 = 6  # species_m.f90:25 nspec0 = 5 -> arrays 0:5
+ABI_VERSION = 1
+
+ODE = {"RK4_ODE": 0, "SG_ODE": 1}
+DERIV = {"cold": 0, "numerical": 1}
+RAY_PARAM = {"arcl": 0, "time": 1}
+EQUILIB = {"slab": 0, "solovev": 1}
+SLAB_BX = {"zero": 0}
+SLAB_BY = {"zero": 0, "constant": 1, "toroid": 2, "linear_shear": 3}
+SLAB_BZ = {"constant": 0, "toroid": 1, "linear": 2, "linear_2": 3}
+SLAB_N = {"constant": 0, "linear": 1, "linear_2": 2, "parabolic": 3, "Gaussian": 4}
+SLAB_T = {"zero": 0, "constant": 1, "linear": 2, "linear_2": 3, "parabolic": 4}
+SOLOVEV_N = {"constant": 0, "parabolic": 1}
+SOLOVEV_T = {"zero": 0, "parabolic": 2}
+
+# per-ray stop codes <-> reference ode_stop_flag strings (include/rays_hip.h)
+STOP_FLAG_TEXT = {
+    0: "",
+    1: "sout > s_max",
+    2: " nstep > nstep_max",
+    10: "x out_of_bounds",
+    11: "y out_of_bounds",
+    12: "z out_of_bounds",
+    13: "negative_dens",
+    14: "negative_temp",
+    20: "R out_of_box",
+    21: "z out_of_box",
+    30: "infinite Vg",
+    31: "ray stalled",
+    40: "dispersion_residual",
+    41: "infinite_Vg",
+    42: "total_absorption",
+    50: "ODE total error",
+    51: "step number .ge. maxnum",
+    52: "equations stiff",
+    53: "t == tout",
+    54: "relerr or abserr < 0",
+    55: "eps <= 0",
+}
+STOP_CODE = {v: k for k, v in STOP_FLAG_TEXT.items()}
+
+
+class SlabParams(C.Structure):
+    _fields_ = [
+        ("bx_prof_model", C.c_int32), ("by_prof_model", C.c_int32),
+        ("bz_prof_model", C.c_int32), ("dens_prof_model", C.c_int32),
+        ("t_prof_model", C.c_int32 * NS0), ("pad_", C.c_int32 * 2),
+        ("xmin", C.c_double), ("xmax", C.c_double), ("ymin", C.c_double),
+        ("ymax", C.c_double), ("zmin", C.c_double), ("zmax", C.c_double),
+        ("rmaj", C.c_double), ("rmin", C.c_double), ("x0", C.c_double),
+        ("bx0", C.c_double), ("by0", C.c_double), ("bz0", C.c_double),
+        ("LBy_shear_scale", C.c_double), ("LBz_scale", C.c_double), ("dBzdx", C.c_double),
+        ("Ln_scale", C.c_double), ("dndx", C.c_double), ("alphan1", C.c_double),
+        ("alphan2", C.c_double), ("n_min", C.c_double),
+        ("LT_scale", C.c_double), ("dtdx", C.c_double),
+        ("alphat1", C.c_double * NS0), ("alphat2", C.c_double * NS0), ("T_min", C.c_double * NS0),
+    ]
+
+
+class SolovevParams(C.Structure):
+    _fields_ = [
+        ("dens_prof_model", C.c_int32), ("t_prof_model", C.c_int32 * NS0), ("pad_", C.c_int32 * 1),
+        ("rmaj", C.c_double), ("kappa", C.c_double), ("bphi0", C.c_double),
+        ("iota0", C.c_double), ("outer_bound", C.c_double), ("psiB", C.c_double),
+        ("alphan1", C.c_double), ("alphan2", C.c_double),
+        ("alphat1", C.c_double * NS0), ("alphat2", C.c_double * NS0),
+        ("box_rmin", C.c_double), ("box_rmax", C.c_double),
+        ("box_zmin", C.c_double), ("box_zmax", C.c_double),
+    ]
+
+
+class RaysParams(C.Structure):
+    """ctypes image of ``rays_params_t`` (include/rays_hip.h)."""
+
+    _fields_ = [
+        ("abi_version", C.c_int32), ("nv", C.c_int32), ("nspec", C.c_int32),
+        ("nstep_max", C.c_int32), ("ode_solver", C.c_int32), ("ray_deriv", C.c_int32),
+        ("ray_param", C.c_int32), ("equilib_model", C.c_int32),
+        ("integrate_eq_gradients", C.c_int32), ("pad_", C.c_int32 * 3),
+        ("ds", C.c_double), ("s_max", C.c_double),
+        ("omgrf", C.c_double), ("k0", C.c_double),
+        ("clight", C.c_double), ("eps0", C.c_double),
+        ("dispersion_resid_limit", C.c_double),
+        ("rel_err0", C.c_double), ("abs_err0", C.c_double), ("SG_error_limit", C.c_double),
+        ("qs", C.c_double * NS0), ("ms", C.c_double * NS0),
+        ("n0s", C.c_double * NS0), ("t0s", C.c_double * NS0), ("eta", C.c_double * NS0),
+        ("slab", SlabParams), ("solovev", SolovevParams),
+    ]
+
+
+def _f32(x: float) -> float:
+    """A default-real (single precision) Fortran literal widened to double."""
+    return float(np.float32(x))
+
+
+class Constants:
+    """constants_m.f90:36-60 -- note the single-precision literals."""
+
+    pi = _f32(3.1415926535897932385)          # :39
+    clight = _f32(2.997930e8)                 # :42
+    mu0 = pi * _f32(4.0e-7)                   # :43
+    eps0 = 1.0 / (mu0 * (clight * clight))    # :44
+    me = _f32(9.1094e-31)                     # :46
+    mp = _f32(1.6726e-27)                     # :47
+    e = _f32(1.6022e-19)                      # :48
+
+
+# species_m.f90:31-35
+SPEC_NAME0 = ["electron", "hydrogen", "deuterium", "tritium", "3He", "alpha"]
+QS0 = [-1.0, 1.0, 1.0, 1.0, 2.0, 2.0]
+MS0 = [1.0, 1836.0, 3670.0, 5497.0, 5496.0, 7294.0]
+
+
+def _arr(val: Any, n: int, default: Any) -> list:
+    """Namelist array value (scalar | list | {index: v}) -> python list of length n (0-based)."""
+    out = [default] * n
+    if val is None:
+        return out
+    if isinstance(val, dict):
+        for k, v in val.items():
+            if 0 <= k < n:
+                out[k] = v
+    elif isinstance(val, (list, tuple)):
+        for i, v in enumerate(val[:n]):
+            out[i] = v
+    else:
+        out[0] = val
+    return out
+
+
+class ConfigError(ValueError):
+    """A configuration the reference rejects with `stop 1` (or that the device path lacks)."""
+
+
+def _lookup(table: Dict[str, int], name: Any, what: str) -> int:
+    key = str(name).strip()
+    if key not in table:
+        raise ConfigError(f"invalid {what} = {key!r}")
+    return table[key]
+
+
+def params_from_namelist(nml: Dict[str, Dict[str, Any]]) -> RaysParams:
+    """Build ``rays_params_t`` the way `initialize(read_input=.true.)` builds module state."""
+    p = RaysParams()
+    p.abi_version = ABI_VERSION
+    diag = nml.get("diagnostics_list", {})
+    sp = nml.get("species_list", {})
+    rf = nml.get("rf_list", {})
+    damp = nml.get("damping_list", {})
+    eql = nml.get("equilibrium_list", {})
+    ode = nml.get("ode_list", {})
+    sg = nml.get("sg_ode_list", {})
+
+    # ---- species_m.f90:97-168 ------------------------------------------------------------
+    eta = [float(x) for x in _arr(sp.get("eta"), NS0, 0.0)]
+    names = [str(x).strip() for x in _arr(sp.get("spec_name"), NS0, "")]
+    qs = [float(x) for x in _arr(sp.get("qs"), NS0, 0.0)]
+    ms = [float(x) for x in _arr(sp.get("ms"), NS0, 0.0)]
+    t0s_ev = [float(x) for x in _arr(sp.get("t0s_ev"), NS0, 0.0)]
+    names[0], ms[0], qs[0], eta[0] = "electron", 1.0, -1.0, 1.0
+    nspec = 0
+    for i in range(1, NS0):
+        if eta[i] > 0.0:
+            nspec += 1
+            for j in range(1, NS0):
+                if names[nspec] == SPEC_NAME0[j]:
+                    ms[nspec], qs[nspec] = MS0[j], QS0[j]
+    charge = 0.0
+    for i in range(nspec + 1):  # dot_product(qs(:nspec), eta(:nspec))
+        charge += qs[i] * eta[i]
+    if abs(charge) > float(sp.get("neutrality", _f32(1.0e-10))):
+        raise ConfigError(f"charge neutrality violated, charge = {charge}")
+    n0 = float(sp.get("n0", 0.0))
+    p.nspec = nspec
+    for i in range(NS0):
+        p.ms[i] = Constants.me * ms[i]
+        p.qs[i] = Constants.e * qs[i]
+        p.n0s[i] = eta[i] * n0
+        p.t0s[i] = Constants.e * t0s_ev[i]
+        p.eta[i] = eta[i]
+
+    # ---- rf_m.f90:57-95 ------------------------------------------------------------------
+    frf = float(rf.get("frf", 0.0))
+    if frf <= 0.0:
+        raise ConfigError(f"initialize_rf: frf = {frf}")
+    if str(rf.get("ray_dispersion_model", "cold")).strip() != "cold":
+        raise ConfigError("check_save: unimplemented ray_dispersion_model")
+    p.omgrf = 2.0 * Constants.pi * frf
+    p.k0 = p.omgrf / Constants.clight
+    p.clight, p.eps0 = Constants.clight, Constants.eps0
+    p.ray_param = _lookup(RAY_PARAM, rf.get("ray_param", "arcl"), "ray parameter")
+    p.dispersion_resid_limit = float(rf.get("dispersion_resid_limit", 0.0))
+
+    # ---- damping_m: only 'no_damp' is on the round-1 device path ---------------------------
+    if str(damp.get("damping_model", "no_damp")).strip() != "no_damp":
+        raise ConfigError("damping_model /= 'no_damp' is not on the device path yet (SURVEY a17)")
+    if bool(damp.get("multi_spec_damping", False)):
+        raise ConfigError("multi_spec_damping is not on the device path yet")
+
+    # ---- equilibrium ---------------------------------------------------------------------
+    p.equilib_model = _lookup(EQUILIB, eql.get("equilib_model", ""), "equilibrium model")
+    if p.equilib_model == EQUILIB["slab"]:
+        s = nml.get("slab_eq_list", {})
+        q = p.slab
+        q.bx_prof_model = _lookup(SLAB_BX, s.get("bx_prof_model", ""), "bx_prof_model")
+        q.by_prof_model = _lookup(SLAB_BY, s.get("by_prof_model", ""), "by_prof_model")
+        q.bz_prof_model = _lookup(SLAB_BZ, s.get("bz_prof_model", ""), "bz_prof_model")
+        q.dens_prof_model = _lookup(SLAB_N, s.get("dens_prof_model", ""), "dens_prof_model")
+        tm = _arr(s.get("t_prof_model"), NS0, "")
+        for i in range(nspec + 1):
+            q.t_prof_model[i] = _lookup(SLAB_T, tm[i], "t_prof_model")
+        for name in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax", "rmaj", "rmin", "x0", "bx0",
+                     "by0", "bz0", "LBy_shear_scale", "LBz_scale", "dBzdx", "Ln_scale", "dndx",
+                     "alphan1", "alphan2", "n_min", "LT_scale", "dtdx"):
+            setattr(q, name, float(s.get(name.lower(), 0.0)))
+        for name in ("alphat1", "alphat2", "T_min"):
+            vals = _arr(s.get(name.lower()), NS0, 0.0)
+            for i in range(NS0):
+                getattr(q, name)[i] = float(vals[i])
+    else:
+        s = nml.get("solovev_eq_list", {})
+        q = p.solovev
+        q.dens_prof_model = _lookup(SOLOVEV_N, s.get("dens_prof_model", ""), "dens_prof_model")
+        tm = _arr(s.get("t_prof_model"), NS0, "")
+        for i in range(nspec + 1):
+            q.t_prof_model[i] = _lookup(SOLOVEV_T, tm[i], "t_prof_model")
+        for name in ("rmaj", "kappa", "bphi0", "iota0", "outer_bound", "alphan1", "alphan2",
+                     "box_rmin", "box_rmax", "box_zmin", "box_zmax"):
+            setattr(q, name, float(s.get(name, 0.0)))
+        for name in ("alphat1", "alphat2"):
+            vals = _arr(s.get(name), NS0, 0.0)
+            for i in range(NS0):
+                getattr(q, name)[i] = float(vals[i])
+        # solovev_eq_m.f90:89-92
+        bp0 = q.bphi0 * q.iota0
+        t = q.outer_bound * q.outer_bound - q.rmaj * q.rmaj
+        q.psiB = 0.5 * bp0 * (t * t) / (q.rmaj * q.rmaj) / 4.0
+
+    # ---- ode_m.f90:113-178, SG_ode_m.f90:37-69 ---------------------------------------------
+    p.ode_solver = _lookup(ODE, ode.get("ode_solver_name", ""), "ode solver")
+    p.ray_deriv = _lookup(DERIV, ode.get("ray_deriv_name", ""), "ray_deriv_name")
+    p.nstep_max = int(ode.get("nstep_max", 0))
+    p.s_max = float(ode.get("s_max", 0.0))
+    p.ds = float(ode.get("ds", 0.0))
+    p.integrate_eq_gradients = 1 if bool(diag.get("integrate_eq_gradients", False)) else 0
+    p.nv = 7 + (5 if p.integrate_eq_gradients else 0)
+    p.rel_err0 = float(sg.get("rel_err0", 0.0))
+    p.abs_err0 = float(sg.get("abs_err0", 0.0))
+    p.SG_error_limit = float(sg.get("sg_error_limit", _f32(0.1)))
+    if p.ode_solver == ODE["SG_ODE"]:
+        lim = _f32(1.0e-10)  # SG_ode_m.f90:63
+        if p.rel_err0 < lim or p.abs_err0 < lim:
+            raise ConfigError("initialize_SG_ode: rel_err0, abs_err0 too small")
+    return p
+
+
+def params_bytes(p: RaysParams) -> bytes:
+    return bytes(memoryview(p))
+
+
+def copy_params(p: RaysParams) -> RaysParams:
+    q = RaysParams()
+    C.memmove(C.byref(q), C.byref(p), C.sizeof(RaysParams))
+    return q

@@ -1,0 +1,50 @@
+"""Reader for the raw dumps written by oracle/ref_dump_driver.f90 (test infrastructure)."""
+from __future__ import annotations
+
+import numpy as np
+
+MAGIC = 0x52415953
+
+
+def read_dump(path: str) -> dict:
+    b = open(path, "rb").read()
+    hdr = np.frombuffer(b, dtype="<i4", count=8)
+    assert int(hdr[0]) == MAGIC and int(hdr[1]) == 2, hdr
+    nray, nv, nstep_max, nspec, probe_stride = (int(x) for x in hdr[2:7])
+    off = 32
+    out = dict(nray=nray, nv=nv, nstep_max=nstep_max, nspec=nspec)
+
+    def take(dtype, count, shape=None):
+        nonlocal off
+        a = np.frombuffer(b, dtype=dtype, count=count, offset=off)
+        off += a.nbytes
+        return a.reshape(shape) if shape else a
+
+    sc = take("<f8", 8)
+    for k, v in zip(("omgrf", "k0", "clight", "eps0", "ds", "s_max", "dispersion_resid_limit",
+                     "trace_wall_s"), sc):
+        out[k] = float(v)
+    for k in ("qs", "ms", "n0s", "t0s", "eta"):
+        out[k] = take("<f8", 6).copy()
+    sol = take("<f8", 6)
+    out["solovev"] = dict(zip(("rmaj", "kappa", "bphi0", "iota0", "outer_bound", "psiB"),
+                              (float(x) for x in sol)))
+    out["rvec0"] = take("<f8", 3 * nray, (nray, 3)).copy()
+    out["rindex_vec0"] = take("<f8", 3 * nray, (nray, 3)).copy()
+    out["npoints"] = take("<i4", nray).copy()
+    flags = take("S60", nray)
+    out["stop_flag"] = [f.decode().rstrip() for f in flags]
+    npt = nstep_max + 1
+    out["ray_vec"] = take("<f8", nv * npt * nray, (nray, npt, nv))
+    out["residual"] = take("<f8", npt * nray, (nray, npt))
+    out["end_ray_vec"] = take("<f8", nv * nray, (nray, nv)).copy()
+    if probe_stride > 0:
+        nprobe = int(take("<i4", 1)[0])
+        neq = 28 + 12 * (nspec + 1)
+        rec = np.dtype([("iray", "<i4"), ("j", "<i4"), ("v", "<f8", (nv,)), ("eq", "<f8", (neq,)),
+                        ("cold", "<f8", (7,)), ("num", "<f8", (7,)), ("dvds", "<f8", (nv,)),
+                        ("resid", "<f8")])
+        out["probes"] = np.frombuffer(b, dtype=rec, count=nprobe, offset=off).copy()
+        off += rec.itemsize * nprobe
+    assert off == len(b), (off, len(b))
+    return out
