@@ -178,6 +178,13 @@ int rays_hip_trace_device(const rays_params_t* p, int nray,
  * scripts: matches the rocprofv3 kernel-trace name prefix). */
 const char* rays_hip_kernel_name(const rays_params_t* p);
 
+/* Diagnostic entry used by the parity tests: evaluates equilibrium + deriv_cold + deriv_num +
+ * eqn_ray + check_save at n states on the current device (host pointers; nv must be 7, nspec 1|2).
+ * cold7/num7[n][7] = dddx(3) dddk(3) dddw; dvds[n][7]; resid[n]; codes[n][4] = equilibrium err,
+ * eqn_ray stop code, check_save flag, check_save stop_ode. */
+int rays_hip_probe(const rays_params_t* p, int n, const double* v, double* cold7, double* num7,
+                   double* dvds, double* resid, int32_t* codes);
+
 #ifdef __cplusplus
 }
 #endif

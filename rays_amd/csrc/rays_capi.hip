@@ -1,0 +1,468 @@
+// rays_capi.hip -- the C ABI of librays_hip.so (include/rays_hip.h).
+//
+// Host side of the drop-in boundary for `call trace_rays` (RAYS_project/RAYS_lib/ray_tracing.f90).
+// No oracle, no CPU fallback: every entry point either runs the HIP kernels or fails with an
+// error message.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/rays_hip.h"
+#include "rays_launch.hpp"
+
+namespace rays {
+#define RAYS_DECL_ENTRIES(s, e, d) const KernelEntry* rays_entries_##s##_##e##_##d(int* n);
+RAYS_DECL_ENTRIES(0, 0, 0)
+RAYS_DECL_ENTRIES(0, 0, 1)
+RAYS_DECL_ENTRIES(0, 1, 0)
+RAYS_DECL_ENTRIES(0, 1, 1)
+RAYS_DECL_ENTRIES(1, 0, 0)
+RAYS_DECL_ENTRIES(1, 0, 1)
+RAYS_DECL_ENTRIES(1, 1, 0)
+RAYS_DECL_ENTRIES(1, 1, 1)
+__global__ void probe_kernel(const DevParams P, int eq, int ns, int nv, int n, const double* v,
+                             double* cold7, double* num7, double* dvds, double* resid, int* codes);
+}  // namespace rays
+
+namespace {
+
+thread_local std::string g_err;
+std::mutex g_mu;
+std::vector<int> g_devices;  // devices used by rays_hip_trace
+
+int fail(const std::string& msg) {
+  g_err = msg;
+  return 1;
+}
+int hip_fail(hipError_t e, const char* what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return 2;
+}
+#define HIP_TRY(call)                              \
+  do {                                             \
+    hipError_t e_ = (call);                        \
+    if (e_ != hipSuccess) return hip_fail(e_, #call); \
+  } while (0)
+
+struct FlagText {
+  int code;
+  const char* text;
+};
+const FlagText kFlags[] = {
+    {RAYS_STOP_NONE, ""},
+    {RAYS_STOP_SOUT_GT_SMAX, "sout > s_max"},
+    {RAYS_STOP_NSTEP_MAX, " nstep > nstep_max"},
+    {RAYS_STOP_X_OUT_OF_BOUNDS, "x out_of_bounds"},
+    {RAYS_STOP_Y_OUT_OF_BOUNDS, "y out_of_bounds"},
+    {RAYS_STOP_Z_OUT_OF_BOUNDS, "z out_of_bounds"},
+    {RAYS_STOP_NEGATIVE_DENS, "negative_dens"},
+    {RAYS_STOP_NEGATIVE_TEMP, "negative_temp"},
+    {RAYS_STOP_R_OUT_OF_BOX, "R out_of_box"},
+    {RAYS_STOP_Z_OUT_OF_BOX, "z out_of_box"},
+    {RAYS_STOP_INFINITE_VG_RHS, "infinite Vg"},
+    {RAYS_STOP_RAY_STALLED, "ray stalled"},
+    {RAYS_STOP_DISP_RESIDUAL, "dispersion_residual"},
+    {RAYS_STOP_INFINITE_VG_CHECK, "infinite_Vg"},
+    {RAYS_STOP_TOTAL_ABSORPTION, "total_absorption"},
+    {RAYS_STOP_ODE_TOTAL_ERROR, "ODE total error"},
+    {RAYS_STOP_SG_MAXNUM, "step number .ge. maxnum"},
+    {RAYS_STOP_SG_STIFF, "equations stiff"},
+    {RAYS_STOP_SG_T_EQ_TOUT, "t == tout"},
+    {RAYS_STOP_SG_NEG_ERR, "relerr or abserr < 0"},
+    {RAYS_STOP_SG_EPS_LE_0, "eps <= 0"},
+};
+
+// rays_params_t -> DevParams.  Derived constants use exactly the reference's expressions
+// (this file is compiled -ffp-contract=off; x86-64 SSE2 doubles are IEEE binary64).
+rays::DevParams make_dev_params(const rays_params_t& p) {
+  rays::DevParams d;
+  std::memset(&d, 0, sizeof d);
+  d.nspec = p.nspec;
+  d.nstep_max = p.nstep_max;
+  d.ray_param = p.ray_param;
+  d.nv = p.nv;
+  d.ds = p.ds;
+  d.s_max = p.s_max;
+  d.omgrf = p.omgrf;
+  d.k0 = p.k0;
+  d.clight = p.clight;
+  d.eps0 = p.eps0;
+  d.resid_limit = p.dispersion_resid_limit;
+  d.omgrf2 = p.omgrf * p.omgrf;
+  d.two_over_k0 = 2. / p.k0;
+  d.m2_over_omgrf = -2. / p.omgrf;
+  d.m1_over_omgrf = -1. / p.omgrf;
+  d.rel_err0 = p.rel_err0;
+  d.abs_err0 = p.abs_err0;
+  d.sg_error_limit = p.SG_error_limit;
+  for (int i = 0; i < RAYS_NS0; i++) {
+    d.qs[i] = p.qs[i];
+    d.ms[i] = p.ms[i];
+    d.n0s[i] = p.n0s[i];
+    d.t0s[i] = p.t0s[i];
+    d.eta[i] = p.eta[i];
+    d.qs2[i] = p.qs[i] * p.qs[i];
+    d.eps0ms[i] = p.eps0 * p.ms[i];
+  }
+  // deriv_num.f90:37  delta = 1.e-6 (default-real literal widened to double)
+  d.delta = (double)1.e-6f;
+  d.two_delta = 2. * d.delta;
+  d.omgrf_p = p.omgrf * (1. + d.delta / 2.);
+  d.omgrf_m = p.omgrf * (1. - d.delta / 2.);
+  d.k0_p = d.omgrf_p / p.clight;
+  d.k0_m = d.omgrf_m / p.clight;
+  d.omgrf2_p = d.omgrf_p * d.omgrf_p;
+  d.omgrf2_m = d.omgrf_m * d.omgrf_m;
+  d.omgrf0_delta = p.omgrf * d.delta;
+  const rays_slab_params_t& s = p.slab;
+  d.by_model = s.by_prof_model;
+  d.bz_model = s.bz_prof_model;
+  d.n_model = s.dens_prof_model;
+  for (int i = 0; i < RAYS_NS0; i++) {
+    d.t_model[i] = s.t_prof_model[i];
+    d.s_at1[i] = s.alphat1[i];
+    d.s_at2[i] = s.alphat2[i];
+    d.T_min[i] = s.T_min[i];
+  }
+  d.xmin = s.xmin; d.xmax = s.xmax; d.ymin = s.ymin; d.ymax = s.ymax; d.zmin = s.zmin; d.zmax = s.zmax;
+  d.s_rmaj = s.rmaj; d.s_rmin = s.rmin; d.x0 = s.x0; d.by0 = s.by0; d.bz0 = s.bz0;
+  d.LBy = s.LBy_shear_scale; d.LBz = s.LBz_scale; d.dBzdx = s.dBzdx; d.Ln = s.Ln_scale;
+  d.dndx = s.dndx; d.s_an1 = s.alphan1; d.s_an2 = s.alphan2; d.n_min = s.n_min;
+  d.LT = s.LT_scale; d.dtdx = s.dtdx;
+  d.by0_over_LBy = s.by0 / s.LBy_shear_scale;
+  d.bz0_over_LBz = s.bz0 / s.LBz_scale;
+  d.one_over_Ln = 1.0 / s.Ln_scale;
+  d.one_over_LT = 1. / s.LT_scale;
+  d.rmin2 = s.rmin * s.rmin;
+  const rays_solovev_params_t& v = p.solovev;
+  d.v_n_model = v.dens_prof_model;
+  for (int i = 0; i < RAYS_NS0; i++) {
+    d.v_t_model[i] = v.t_prof_model[i];
+    d.v_at1[i] = v.alphat1[i];
+    d.v_at2[i] = v.alphat2[i];
+  }
+  d.rmaj = v.rmaj; d.kappa = v.kappa; d.bphi0 = v.bphi0; d.psiB = v.psiB;
+  d.v_an1 = v.alphan1; d.v_an2 = v.alphan2;
+  d.box_rmin = v.box_rmin; d.box_rmax = v.box_rmax; d.box_zmin = v.box_zmin; d.box_zmax = v.box_zmax;
+  d.bp0 = v.bphi0 * v.iota0;          // solovev_eq_m.f90:159
+  d.rk = v.rmaj * v.kappa;
+  d.rk2 = d.rk * d.rk;                // (rmaj*kappa)**2
+  d.rmaj2 = v.rmaj * v.rmaj;
+  d.bphi0_rmaj = v.bphi0 * v.rmaj;    // :172
+  d.half_bp0 = .5 * d.bp0;            // :308
+  d.bp0_2 = d.bp0 * 2.;               // :181
+  return d;
+}
+
+const rays::KernelEntry* find_kernel(const rays_params_t& p) {
+  using namespace rays;
+  typedef const KernelEntry* (*Getter)(int*);
+  static const Getter getters[2][2][2] = {
+      {{rays_entries_0_0_0, rays_entries_0_0_1}, {rays_entries_0_1_0, rays_entries_0_1_1}},
+      {{rays_entries_1_0_0, rays_entries_1_0_1}, {rays_entries_1_1_0, rays_entries_1_1_1}}};
+  int n = 0;
+  const KernelEntry* e = getters[p.ode_solver][p.equilib_model][p.ray_deriv](&n);
+  for (int i = 0; i < n; i++)
+    if (e[i].ns == p.nspec + 1 && e[i].nv == p.nv) return &e[i];
+  return nullptr;
+}
+
+// Per-device ring of refill counters (allocated once, outside any stream capture).
+struct DeviceWorkspace {
+  unsigned int* counters = nullptr;
+  int next = 0;
+};
+constexpr int kCounterSlots = 256;
+constexpr int kCounterStride = 32;  // 128 B apart
+std::vector<DeviceWorkspace> g_ws;
+
+int get_counter(unsigned int** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mu);
+  if ((int)g_ws.size() <= dev) g_ws.resize(dev + 1);
+  DeviceWorkspace& w = g_ws[dev];
+  if (!w.counters) HIP_TRY(hipMalloc(&w.counters, sizeof(unsigned int) * kCounterSlots * kCounterStride));
+  *out = w.counters + (size_t)w.next * kCounterStride;
+  w.next = (w.next + 1) % kCounterSlots;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rays_hip_last_error(char* buf, int len) {
+  if (buf && len > 0) {
+    std::snprintf(buf, (size_t)len, "%s", g_err.c_str());
+  }
+  return (int)g_err.size();
+}
+
+const char* rays_hip_stop_flag_text(int stop_code) {
+  for (const FlagText& f : kFlags)
+    if (f.code == stop_code) return f.text;
+  return "";
+}
+
+int rays_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int rays_hip_init(int ngpu) {
+  int n = rays_hip_device_count();
+  if (n <= 0) {
+    g_err = "rays_hip_init: no HIP device visible";
+    return -1;
+  }
+  if (ngpu <= 0 || ngpu > n) ngpu = n;
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_devices.clear();
+  for (int i = 0; i < ngpu; i++) g_devices.push_back(i);
+  return ngpu;
+}
+
+int rays_hip_finalize(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (size_t d = 0; d < g_ws.size(); d++)
+    if (g_ws[d].counters) {
+      hipSetDevice((int)d);
+      hipFree(g_ws[d].counters);
+      g_ws[d].counters = nullptr;
+    }
+  g_devices.clear();
+  return 0;
+}
+
+int rays_hip_check_params(const rays_params_t* p) {
+  if (!p) return fail("rays_hip: null parameter block");
+  if (p->abi_version != RAYS_ABI_VERSION) return fail("rays_hip: rays_params_t ABI version mismatch");
+  if (p->nspec < 0 || p->nspec > RAYS_NSPEC0) return fail("rays_hip: nspec out of range 0..5");
+  if (p->ode_solver != RAYS_ODE_RK4 && p->ode_solver != RAYS_ODE_SG)
+    return fail("ode_solver, invalid ode solver");  // ode_m.f90:246-249
+  if (p->ray_deriv != RAYS_DERIV_COLD && p->ray_deriv != RAYS_DERIV_NUM)
+    return fail("EQN_RAY: invalid value, ray_deriv_name");  // eqn_ray.f90:120-122
+  if (p->ray_param != RAYS_PARAM_ARCL && p->ray_param != RAYS_PARAM_TIME)
+    return fail("EQN_RAY: invalid ray parameter");  // eqn_ray.f90:183-185
+  if (p->equilib_model != RAYS_EQ_SLAB && p->equilib_model != RAYS_EQ_SOLOVEV)
+    return fail("equilibrium_m: invalid equilibrium model (device path: slab | solovev)");
+  if (p->nv != 7 + (p->integrate_eq_gradients ? 5 : 0))
+    return fail("rays_hip: nv must be 7 (+5 with integrate_eq_gradients); damping rows are not on the device path");
+  if (p->nstep_max < 0) return fail("rays_hip: nstep_max < 0");
+  if (p->equilib_model == RAYS_EQ_SOLOVEV) {
+    if (p->solovev.dens_prof_model != RAYS_SOLOVEV_N_CONSTANT && p->solovev.dens_prof_model != RAYS_SOLOVEV_N_PARABOLIC)
+      return fail("solovev_eq invalid dens_prof_model");  // solovev_eq_m.f90:227-229
+    for (int is = 0; is <= p->nspec; is++)
+      if (p->solovev.t_prof_model[is] != RAYS_SOLOVEV_T_ZERO && p->solovev.t_prof_model[is] != RAYS_SOLOVEV_T_PARABOLIC)
+        return fail("SOLOVEV: t_prof_model must be 'zero' or 'parabolic' ('constant' leaves ts undefined in the reference)");
+  } else {
+    const rays_slab_params_t& s = p->slab;
+    if (s.bx_prof_model != RAYS_SLAB_BX_ZERO) return fail("SLAB: invalid bx_prof_model");
+    if (s.by_prof_model < 0 || s.by_prof_model > RAYS_SLAB_BY_LINEAR_SHEAR) return fail("SLAB: invalid by_prof_model");
+    if (s.bz_prof_model < 0 || s.bz_prof_model > RAYS_SLAB_BZ_LINEAR_2) return fail("SLAB: invalid bz_prof_model");
+    if (s.dens_prof_model < 0 || s.dens_prof_model > RAYS_SLAB_N_GAUSSIAN) return fail("SLAB: invalid dens_prof_model");
+    for (int is = 0; is <= p->nspec; is++)
+      if (s.t_prof_model[is] < 0 || s.t_prof_model[is] > RAYS_SLAB_T_PARABOLIC) return fail("SLAB: invalid t_prof_model");
+  }
+  if (p->ode_solver == RAYS_ODE_SG && (p->rel_err0 < (double)1.e-10f || p->abs_err0 < (double)1.e-10f))
+    return fail("initialize_SG_ode: rel_err0, abs_err0 too small");  // SG_ode_m.f90:63-66
+  if (!find_kernel(*p)) return fail("rays_hip: no kernel specialisation for this configuration");
+  return 0;
+}
+
+const char* rays_hip_kernel_name(const rays_params_t* p) {
+  if (!p || rays_hip_check_params(p)) return "";
+  return find_kernel(*p)->name;
+}
+
+int rays_hip_trace_device(const rays_params_t* p, int nray, const double* d_rvec0,
+                          const double* d_rindex_vec0, double* d_ray_vec, double* d_residual,
+                          int32_t* d_npoints, int32_t* d_stop_code, double* d_end_ray_vec,
+                          double* d_end_residuals, double* d_max_residuals, void* hip_stream,
+                          int flags) {
+  int rc = rays_hip_check_params(p);
+  if (rc) return rc;
+  if (nray < 0) return fail("rays_hip_trace_device: nray < 0");
+  if (nray == 0) return 0;
+  if (!d_rvec0 || !d_rindex_vec0 || !d_ray_vec || !d_residual || !d_npoints || !d_stop_code)
+    return fail("rays_hip_trace_device: null device pointer");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  const size_t npt = (size_t)p->nstep_max + 1;
+  if (!(flags & RAYS_TRACE_NO_ZERO_FILL)) {  // ray_results_m.f90:154-164
+    HIP_TRY(hipMemsetAsync(d_ray_vec, 0, sizeof(double) * npt * (size_t)p->nv * (size_t)nray, stream));
+    HIP_TRY(hipMemsetAsync(d_residual, 0, sizeof(double) * npt * (size_t)nray, stream));
+  }
+  unsigned int* counter = nullptr;
+  rc = get_counter(&counter);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned int), stream));
+  rays::TraceArgs A;
+  A.nray = nray;
+  A.rvec0 = d_rvec0;
+  A.rindex_vec0 = d_rindex_vec0;
+  A.ray_vec = d_ray_vec;
+  A.residual = d_residual;
+  A.npoints = d_npoints;
+  A.stop_code = d_stop_code;
+  A.end_ray_vec = d_end_ray_vec;
+  A.end_residuals = d_end_residuals;
+  A.max_residuals = d_max_residuals;
+  A.next_ray = counter;
+  const rays::DevParams D = make_dev_params(*p);
+  int grid = 0;
+  hipError_t e = find_kernel(*p)->launch(D, A, stream, &grid);
+  if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  return 0;
+}
+
+// One device's share of rays_hip_trace: rays [r0, r1) -> contiguous slabs of the host arrays.
+static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1, const double* rvec0,
+                                 const double* rindex_vec0, double* ray_vec, double* residual,
+                                 int32_t* npoints, int32_t* stop_code, double* end_ray_vec,
+                                 double* end_residuals, double* max_residuals, std::string* err) {
+  auto bail = [&](int rc) {
+    *err = g_err;
+    return rc;
+  };
+#define DEV_TRY(call)                                      \
+  do {                                                     \
+    hipError_t e_ = (call);                                \
+    if (e_ != hipSuccess) return bail(hip_fail(e_, #call)); \
+  } while (0)
+  const int n = r1 - r0;
+  if (n <= 0) return 0;
+  const size_t npt = (size_t)p->nstep_max + 1, nv = (size_t)p->nv;
+  DEV_TRY(hipSetDevice(dev));
+  hipStream_t st;
+  DEV_TRY(hipStreamCreate(&st));
+  double *d_r = nullptr, *d_n = nullptr, *d_rv = nullptr, *d_res = nullptr, *d_ev = nullptr, *d_er = nullptr,
+         *d_mr = nullptr;
+  int32_t *d_np = nullptr, *d_sc = nullptr;
+  int rc = 0;
+  do {
+#define DEV_CHK(call)                        \
+  {                                          \
+    hipError_t e_ = (call);                  \
+    if (e_ != hipSuccess) {                  \
+      rc = bail(hip_fail(e_, #call));        \
+      break;                                 \
+    }                                        \
+  }
+    DEV_CHK(hipMalloc(&d_r, sizeof(double) * 3 * n));
+    DEV_CHK(hipMalloc(&d_n, sizeof(double) * 3 * n));
+    DEV_CHK(hipMalloc(&d_rv, sizeof(double) * npt * nv * n));
+    DEV_CHK(hipMalloc(&d_res, sizeof(double) * npt * n));
+    DEV_CHK(hipMalloc(&d_np, sizeof(int32_t) * n));
+    DEV_CHK(hipMalloc(&d_sc, sizeof(int32_t) * n));
+    DEV_CHK(hipMalloc(&d_ev, sizeof(double) * nv * n));
+    DEV_CHK(hipMalloc(&d_er, sizeof(double) * n));
+    DEV_CHK(hipMalloc(&d_mr, sizeof(double) * n));
+    DEV_CHK(hipMemcpyAsync(d_r, rvec0 + 3 * (size_t)r0, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
+    DEV_CHK(hipMemcpyAsync(d_n, rindex_vec0 + 3 * (size_t)r0, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
+    rc = rays_hip_trace_device(p, n, d_r, d_n, d_rv, d_res, d_np, d_sc, d_ev, d_er, d_mr, st, 0);
+    if (rc) {
+      bail(rc);
+      break;
+    }
+    DEV_CHK(hipMemcpyAsync(ray_vec + npt * nv * (size_t)r0, d_rv, sizeof(double) * npt * nv * n, hipMemcpyDeviceToHost, st));
+    DEV_CHK(hipMemcpyAsync(residual + npt * (size_t)r0, d_res, sizeof(double) * npt * n, hipMemcpyDeviceToHost, st));
+    DEV_CHK(hipMemcpyAsync(npoints + r0, d_np, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    DEV_CHK(hipMemcpyAsync(stop_code + r0, d_sc, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    if (end_ray_vec) DEV_CHK(hipMemcpyAsync(end_ray_vec + nv * (size_t)r0, d_ev, sizeof(double) * nv * n, hipMemcpyDeviceToHost, st));
+    if (end_residuals) DEV_CHK(hipMemcpyAsync(end_residuals + r0, d_er, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    if (max_residuals) DEV_CHK(hipMemcpyAsync(max_residuals + r0, d_mr, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    DEV_CHK(hipStreamSynchronize(st));
+  } while (0);
+  hipFree(d_r); hipFree(d_n); hipFree(d_rv); hipFree(d_res); hipFree(d_np); hipFree(d_sc);
+  hipFree(d_ev); hipFree(d_er); hipFree(d_mr);
+  hipStreamDestroy(st);
+  return rc;
+#undef DEV_CHK
+#undef DEV_TRY
+}
+
+int rays_hip_trace(const rays_params_t* p, int nray, const double* rvec0, const double* rindex_vec0,
+                   double* ray_vec, double* residual, int32_t* npoints, int32_t* stop_code,
+                   double* end_ray_vec, double* end_residuals, double* max_residuals,
+                   double* elapsed_s) {
+  int rc = rays_hip_check_params(p);
+  if (rc) return rc;
+  if (nray < 0) return fail("rays_hip_trace: nray < 0");
+  if (nray > 0 && (!rvec0 || !rindex_vec0 || !ray_vec || !residual || !npoints || !stop_code))
+    return fail("rays_hip_trace: null array argument");
+  std::vector<int> devs;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    devs = g_devices;
+  }
+  if (devs.empty()) {
+    if (rays_hip_init(0) < 0) return 3;
+    std::lock_guard<std::mutex> lk(g_mu);
+    devs = g_devices;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  const int G = (int)devs.size();
+  // contiguous blocks, like the reference's OpenMP schedule(static) (ray_tracing.f90:62)
+  const int per = (nray + G - 1) / G;
+  std::vector<int> rcs(G, 0);
+  std::vector<std::string> errs(G);
+  std::vector<std::thread> th;
+  for (int g = 0; g < G; g++) {
+    const int r0 = std::min(nray, g * per), r1 = std::min(nray, (g + 1) * per);
+    th.emplace_back([&, g, r0, r1] {
+      rcs[g] = trace_block_on_device(devs[g], p, r0, r1, rvec0, rindex_vec0, ray_vec, residual, npoints,
+                                     stop_code, end_ray_vec, end_residuals, max_residuals, &errs[g]);
+    });
+  }
+  for (auto& t : th) t.join();
+  for (int g = 0; g < G; g++)
+    if (rcs[g]) {
+      g_err = errs[g];
+      return rcs[g];
+    }
+  if (elapsed_s)
+    *elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return 0;
+}
+
+// Diagnostic entry (tests): evaluate the RHS pieces at n states on the current device.
+// v[n][nv] host; outputs host: cold7[n][7], num7[n][7], dvds[n][nv], resid[n], codes[n][4]
+// (codes: equilibrium err, eqn_ray stop code, check_save flag, check_save stop_ode).
+int rays_hip_probe(const rays_params_t* p, int n, const double* v, double* cold7, double* num7,
+                   double* dvds, double* resid, int32_t* codes) {
+  int rc = rays_hip_check_params(p);
+  if (rc) return rc;
+  if (n <= 0) return 0;
+  const size_t nv = (size_t)p->nv;
+  double *d_v = nullptr, *d_c = nullptr, *d_n = nullptr, *d_f = nullptr, *d_r = nullptr;
+  int* d_k = nullptr;
+  HIP_TRY(hipMalloc(&d_v, sizeof(double) * nv * n));
+  HIP_TRY(hipMalloc(&d_c, sizeof(double) * 7 * n));
+  HIP_TRY(hipMalloc(&d_n, sizeof(double) * 7 * n));
+  HIP_TRY(hipMalloc(&d_f, sizeof(double) * nv * n));
+  HIP_TRY(hipMalloc(&d_r, sizeof(double) * n));
+  HIP_TRY(hipMalloc(&d_k, sizeof(int) * 4 * n));
+  HIP_TRY(hipMemcpy(d_v, v, sizeof(double) * nv * n, hipMemcpyHostToDevice));
+  const rays::DevParams D = make_dev_params(*p);
+  hipLaunchKernelGGL(rays::probe_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, D, p->equilib_model,
+                     p->nspec + 1, p->nv, n, d_v, d_c, d_n, d_f, d_r, d_k);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(cold7, d_c, sizeof(double) * 7 * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(num7, d_n, sizeof(double) * 7 * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(dvds, d_f, sizeof(double) * nv * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(resid, d_r, sizeof(double) * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(codes, d_k, sizeof(int) * 4 * n, hipMemcpyDeviceToHost));
+  hipFree(d_v); hipFree(d_c); hipFree(d_n); hipFree(d_f); hipFree(d_r); hipFree(d_k);
+  return 0;
+}
+
+}  // extern "C"

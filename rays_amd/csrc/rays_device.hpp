@@ -1,0 +1,754 @@
+// rays_device.hpp -- gfx950 device functions of the RAYS ray-equation right-hand side.
+//
+// One ray per lane; everything here is straight-line FP64 scalar algebra per lane (no MFMA: the
+// RHS is a cold-plasma dispersion determinant and its derivatives, not a contraction).  All
+// configuration that the reference selects with strings inside its hot loop
+// (ode_m.f90:238, eqn_ray.f90:106,148, equilibrium_m.f90:177, slab_eq_m.f90:172-300) is either a
+// template parameter (equilibrium model, species count, derivative model) or a wave-uniform
+// branch on kernel-argument data (profile models, ray_param), so lanes never diverge on it.
+//
+// Numerics contract: IEEE binary64, evaluated in the reference's operation order so that results
+// are bit-identical to the Fortran CPU path wherever libm (pow/exp) is not involved.  This file
+// must be compiled with -ffp-contract=off and without fast-math; NaN polarity of every comparison
+// is part of the contract.
+//
+// Citations are RAYS_project/RAYS_lib/<file>:<line>.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/rays_hip.h"
+
+namespace rays {
+
+#define RAYS_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------------
+// Device parameter block: rays_params_t trimmed to what the kernels read, plus values the
+// reference recomputes from constants on every call (same IEEE operations, done once on the host
+// by make_dev_params() in rays_capi.hip, compiled -ffp-contract=off).
+// Passed by value as a kernel argument -> lives in the kernarg segment, fetched with scalar loads.
+// ---------------------------------------------------------------------------------------------
+struct DevParams {
+  int nspec, nstep_max, ray_param, nv;
+  double ds, s_max, omgrf, k0, clight, eps0, resid_limit;
+  double omgrf2;               // omgrf**2                      equilibrium_m.f90:264
+  double two_over_k0;          // 2./k0                         deriv_cold.f90:51
+  double m2_over_omgrf;        // -2./omgrf                     deriv_cold.f90:73-74
+  double m1_over_omgrf;        // -1./omgrf                     deriv_cold.f90:75
+  double rel_err0, abs_err0, sg_error_limit;
+  double qs[RAYS_NS0], ms[RAYS_NS0], n0s[RAYS_NS0], t0s[RAYS_NS0], eta[RAYS_NS0];
+  double qs2[RAYS_NS0];        // qs**2                         equilibrium_m.f90:263
+  double eps0ms[RAYS_NS0];     // eps0*ms                       equilibrium_m.f90:263
+  // numerical-derivative constants (deriv_num.f90:37,72-80)
+  double delta, two_delta, omgrf_p, omgrf_m, k0_p, k0_m, omgrf2_p, omgrf2_m, omgrf0_delta;
+  // slab
+  int by_model, bz_model, n_model;
+  int t_model[RAYS_NS0];
+  double xmin, xmax, ymin, ymax, zmin, zmax;
+  double s_rmaj, s_rmin, x0, by0, bz0, LBy, LBz, dBzdx, Ln, dndx, s_an1, s_an2, n_min, LT, dtdx;
+  double s_at1[RAYS_NS0], s_at2[RAYS_NS0], T_min[RAYS_NS0];
+  double by0_over_LBy, bz0_over_LBz, one_over_Ln, one_over_LT, rmin2;
+  // solovev
+  int v_n_model;
+  int v_t_model[RAYS_NS0];
+  double rmaj, kappa, bphi0, psiB, v_an1, v_an2;
+  double v_at1[RAYS_NS0], v_at2[RAYS_NS0];
+  double box_rmin, box_rmax, box_zmin, box_zmax;
+  double bp0, rk, rk2, rmaj2, bphi0_rmaj, half_bp0, bp0_2;
+};
+
+RAYS_DEV double sq(double x) { return x * x; }
+RAYS_DEV double pow4(double x) { return ((x * x) * x) * x; }  // flang lowers x**4 sequentially
+
+// pow with the exact IEEE identities short-circuited (wave-uniform on the exponent): the BASELINE
+// profiles use exponents 1 and 0 (alphan1 = alphan2 = 1), for which pow is exact by definition.
+RAYS_DEV double pow_u(double x, double y) {
+  if (y == 1.0) return x;
+  if (y == 0.0) return 1.0;
+  return pow(x, y);
+}
+
+// compiler-rt __divdc3 restricted to (a + 0i)/(c + 0i) -> real part; what flang emits for
+// real/complex and complex/real quotients (check_save.f90:226, suscep_m.f90:75).
+RAYS_DEV double divdc3_real(double a, double c) {
+  double fc = fabs(c);
+  int k = 0;
+  // logb(|c|) finite <=> c finite and non-zero
+  if (fc > 0.0 && fc < __builtin_inf()) {
+    k = ilogb(fc);
+    c = scalbn(c, -k);
+  }
+  double denom = c * c;
+  return scalbn((a * c) / denom, -k);
+}
+
+// ---------------------------------------------------------------------------------------------
+// type eq_point (equilibrium_m.f90:39-59), NS = nspec+1 live species.
+// gbt[i][j] = gradbtensor(i+1,j+1) = dB(j)/dx(i).
+// ---------------------------------------------------------------------------------------------
+template <int NS>
+struct EqPoint {
+  double bvec[3], bmag, gradbmag[3], bunit[3], gradbunit[3][3], gbt[3][3];
+  double ns[NS], gradns[NS][3], ts0, gradts0[3];
+  double alpha[NS], gamma[NS];
+  int err;
+};
+
+// parabolic_prof            slab_eq_m.f90:354-381  (fp := 0 where the reference leaves it undefined)
+RAYS_DEV void parabolic_prof(double rho, double f_min, double a1, double a2, double& f, double& fp) {
+  f = 0.0;
+  fp = 0.0;
+  if (rho < 1.0) {
+    double pr = pow_u(rho, a2);
+    f = pow_u(1. - pr, a1);
+    fp = -a1 * a2 * pow_u(rho, a2 - 1.) * pow_u(1. - pr, a1 - 1.);
+  }
+  if (f < f_min) {
+    f = f_min;
+    fp = 0.0;
+  }
+}
+
+// slab_eq                   slab_eq_m.f90:125-309
+template <int NS>
+RAYS_DEV int slab_fields(const DevParams& P, const double rvec[3], double bvec[3], double gbt[3][3],
+                         double ns[NS], double gradns[NS][3], double ts[NS], double gradts[NS][3],
+                         bool check_box) {
+  int err = 0;
+  const double x = rvec[0], y = rvec[1], z = rvec[2];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) gbt[i][j] = 0.;
+#pragma unroll
+  for (int is = 0; is < NS; is++) {
+    ns[is] = 0.;
+    ts[is] = 0.;
+#pragma unroll
+    for (int i = 0; i < 3; i++) gradns[is][i] = gradts[is][i] = 0.;
+  }
+  if (x < P.xmin || x > P.xmax) err = RAYS_STOP_X_OUT_OF_BOUNDS;  // :163
+  if (y < P.ymin || y > P.ymax) err = RAYS_STOP_Y_OUT_OF_BOUNDS;  // :164
+  if (z < P.zmin || z > P.zmax) err = RAYS_STOP_Z_OUT_OF_BOUNDS;  // :165
+  if (!check_box) err = 0;
+
+  bvec[0] = 0.;
+  bvec[1] = 0.;
+  if (P.by_model == RAYS_SLAB_BY_CONSTANT) {  // :184-206
+    bvec[1] = P.by0;
+  } else if (P.by_model == RAYS_SLAB_BY_TOROID) {
+    bvec[1] = P.by0 / (1. + x / P.s_rmaj);
+    gbt[0][1] = -bvec[1] / (P.s_rmaj + x);
+  } else if (P.by_model == RAYS_SLAB_BY_LINEAR_SHEAR) {
+    bvec[1] = P.by0 * x / P.LBy;
+    gbt[0][1] = P.by0_over_LBy;
+  }
+  if (P.bz_model == RAYS_SLAB_BZ_CONSTANT) {  // :209-233
+    bvec[2] = P.bz0;
+  } else if (P.bz_model == RAYS_SLAB_BZ_TOROID) {
+    bvec[2] = P.bz0 / (1. + x / P.s_rmaj);
+    gbt[0][2] = -bvec[2] / (P.s_rmaj + x);
+  } else if (P.bz_model == RAYS_SLAB_BZ_LINEAR) {
+    bvec[2] = P.bz0 * (1. + x / P.LBz);
+    gbt[0][2] = P.bz0_over_LBz;
+  } else {
+    bvec[2] = P.bz0 + P.dBzdx * (x - P.x0);
+    gbt[0][2] = P.dBzdx;
+  }
+  if (P.n_model == RAYS_SLAB_N_CONSTANT) {  // :237-267
+#pragma unroll
+    for (int is = 0; is < NS; is++) ns[is] = P.n0s[is];
+  } else if (P.n_model == RAYS_SLAB_N_LINEAR) {
+    const double f = 1.0 + x / P.Ln;
+#pragma unroll
+    for (int is = 0; is < NS; is++) {
+      ns[is] = P.n0s[is] * f;
+      gradns[is][0] = P.n0s[is] * P.one_over_Ln;
+    }
+  } else if (P.n_model == RAYS_SLAB_N_LINEAR_2) {  // value/gradient inconsistency kept (:249-250)
+#pragma unroll
+    for (int is = 0; is < NS; is++) {
+      ns[is] = P.n0s[is] + P.dndx * P.eta[is] * (x - P.x0);
+      gradns[is][0] = P.n0s[is] * P.dndx;
+    }
+  } else if (P.n_model == RAYS_SLAB_N_PARABOLIC) {
+    double f, fp;
+    parabolic_prof(x, P.n_min, P.s_an1, P.s_an2, f, fp);
+#pragma unroll
+    for (int is = 0; is < NS; is++) {
+      ns[is] = P.n0s[is] * f;
+      gradns[is][0] = P.n0s[is] * fp;
+    }
+  } else {  // Gaussian
+    const double g = exp(-3. * P.s_an1 * sq(x / P.s_rmin));
+    const double gp = -6. * P.s_an1 * x / P.rmin2;
+#pragma unroll
+    for (int is = 0; is < NS; is++) {
+      ns[is] = P.n0s[is] * g;
+      gradns[is][0] = ns[is] * gp;
+    }
+  }
+#pragma unroll
+  for (int is = 0; is < NS; is++) {  // :270-301
+    const int m = P.t_model[is];
+    if (m == RAYS_SLAB_T_CONSTANT) {
+      ts[is] = P.t0s[is];
+    } else if (m == RAYS_SLAB_T_LINEAR) {
+      ts[is] = P.t0s[is] * (1. + x / P.LT);
+      gradts[is][0] = P.t0s[is] * P.one_over_LT;
+    } else if (m == RAYS_SLAB_T_LINEAR_2) {
+      ts[is] = P.t0s[is] + P.dtdx * (x - P.x0);
+      gradts[is][0] = P.t0s[is] * P.dtdx;
+    } else if (m == RAYS_SLAB_T_PARABOLIC) {
+      double f, fp;
+      parabolic_prof(x - P.x0, P.T_min[is], P.s_at1[is], P.s_at2[is], f, fp);
+      ts[is] = P.t0s[is] * f;
+      gradts[is][0] = P.t0s[is] * fp;
+    }
+  }
+  if (check_box && err == 0) {  // :305-306 (only reached in-box)
+    double mn = ns[0], mt = ts[0];
+#pragma unroll
+    for (int is = 1; is < NS; is++) {
+      if (ns[is] < mn) mn = ns[is];
+      if (ts[is] < mt) mt = ts[is];
+    }
+    if (mn < 0.) err = RAYS_STOP_NEGATIVE_DENS;
+    if (mt < 0.) err = RAYS_STOP_NEGATIVE_TEMP;
+  }
+  return err;
+}
+
+// solovev_eq + solovev_psi  solovev_eq_m.f90:122-276, 280-322
+template <int NS>
+RAYS_DEV int solovev_fields(const DevParams& P, const double rvec[3], double bvec[3],
+                            double gbt[3][3], double ns[NS], double gradns[NS][3], double ts[NS],
+                            double gradts[NS][3], bool check_box) {
+  int err = 0;
+  const double x = rvec[0], y = rvec[1], z = rvec[2];
+  const double r = sqrt(x * x + y * y);
+  if (r < P.box_rmin || r > P.box_rmax) err = RAYS_STOP_R_OUT_OF_BOX;  // :155
+  if (z < P.box_zmin || z > P.box_zmax) err = RAYS_STOP_Z_OUT_OF_BOX;  // :156
+  if (!check_box) err = 0;
+  const double bp0 = P.bp0;
+  // :170-172 (the same br, bz appear in solovev_psi :312-313)
+  const double br = -bp0 * r * z / P.rk2;
+  const double bz = bp0 * (sq(z / P.rk) + .5 * (sq(r / P.rmaj) - 1.));
+  // solovev_psi :308-318
+  const double psi = P.half_bp0 * (sq(r * z / P.rk) + (sq(r * r - P.rmaj2)) / P.rmaj2 / 4.);
+  const double gradpsi[3] = {x * bz, y * bz, -r * br};
+  const double psiN = psi / P.psiB;
+  const double gradpsiN[3] = {gradpsi[0] / P.psiB, gradpsi[1] / P.psiB, gradpsi[2] / P.psiB};
+
+  const double bphi = P.bphi0_rmaj / r;
+  const double dbrdr = br / r;
+  const double dbrdz = -bp0 * r / P.rk2;
+  const double dbzdr = bp0 * r / P.rmaj2;
+  const double dbzdz = P.bp0_2 * z / P.rk2;
+  const double dbphidr = -bphi / r;
+  bvec[0] = br * x / r - bphi * y / r;  // :187-189
+  bvec[1] = br * y / r + bphi * x / r;
+  bvec[2] = bz;
+  const double r2 = sq(r), x2 = sq(x), y2 = sq(y);
+  gbt[0][0] = (dbrdr * x2 + br * y2 / r + (-dbphidr + bphi / r) * x * y) / r2;  // :192-204
+  gbt[1][0] = ((dbrdr - br / r) * x * y - dbphidr * y2 - bphi * x2 / r) / r2;
+  gbt[2][0] = dbrdz * x / r;
+  gbt[0][1] = ((dbrdr - br / r) * x * y + dbphidr * x2 + bphi * y2 / r) / r2;
+  gbt[1][1] = (dbrdr * y2 + br * x2 / r + (dbphidr - bphi / r) * x * y) / r2;
+  gbt[2][1] = dbrdz * y / r;
+  gbt[0][2] = dbzdr * x / r;
+  gbt[1][2] = dbzdr * y / r;
+  gbt[2][2] = dbzdz;
+
+#pragma unroll
+  for (int is = 0; is < NS; is++) {
+    ns[is] = 0.;
+    ts[is] = 0.;
+#pragma unroll
+    for (int i = 0; i < 3; i++) gradns[is][i] = gradts[is][i] = 0.;
+  }
+  if (P.v_n_model == RAYS_SOLOVEV_N_CONSTANT) {  // :210-212
+#pragma unroll
+    for (int is = 0; is < NS; is++) ns[is] = P.n0s[is];
+  } else if (psiN < 1.0) {  // :214-225
+    const double a1 = P.v_an1, a2 = P.v_an2;
+    const double pr = pow_u(psiN, a2);
+    const double prof = pow_u(1. - pr, a1);
+    const double dd_psi = -a1 * a2 * pow_u(psiN, a2 - 1.) * pow_u(1. - pr, a1 - 1.);
+#pragma unroll
+    for (int is = 0; is < NS; is++) {
+      ns[is] = P.n0s[is] * prof;
+      const double c = P.n0s[is] * dd_psi;
+      gradns[is][0] = c * gradpsiN[0];
+      gradns[is][1] = c * gradpsiN[1];
+      gradns[is][2] = c * gradpsiN[2];
+    }
+  }
+  // temperature :235-268 -- 'parabolic' zeroes the whole ts/gradts arrays inside the species loop
+  // and uses exponent alphat1 in the gradient: kept as in the reference.
+#pragma unroll
+  for (int is = 0; is < NS; is++) {
+    if (P.v_t_model[is] == RAYS_SOLOVEV_T_PARABOLIC) {
+#pragma unroll
+      for (int j = 0; j < NS; j++) {
+        ts[j] = 0.;
+        gradts[j][0] = gradts[j][1] = gradts[j][2] = 0.;
+      }
+      if (psiN < 1.) {
+        const double a1 = P.v_at1[is], a2 = P.v_at2[is];
+        const double pf = pow_u(1. - pow_u(psiN, a2), a1);
+        ts[is] = P.t0s[is] * pf;
+        const double dd_psi = -a1 * a2 * pow_u(psiN, a2 - 1.) * pf;
+        const double c = P.t0s[is] * dd_psi;
+        gradts[is][0] = c * gradpsiN[0];
+        gradts[is][1] = c * gradpsiN[1];
+        gradts[is][2] = c * gradpsiN[2];
+      }
+    }
+  }
+  if (check_box && err == 0) {  // :272-273
+    double mn = ns[0], mt = ts[0];
+#pragma unroll
+    for (int is = 1; is < NS; is++) {
+      if (ns[is] < mn) mn = ns[is];
+      if (ts[is] < mt) mt = ts[is];
+    }
+    if (mn < 0.) err = RAYS_STOP_NEGATIVE_DENS;
+    if (mt < 0.) err = RAYS_STOP_NEGATIVE_TEMP;
+  }
+  return err;
+}
+
+// equilibrium               equilibrium_m.f90:135-272
+// omgrf / omgrf2 are arguments because deriv_num re-evaluates the equilibrium at omgrf(1 +- delta/2)
+// (deriv_num.f90:72-79); on the device these are per-call values, which also removes the
+// reference's data race on the module variables.
+template <int EQ, int NS>
+RAYS_DEV void equilibrium(const DevParams& P, double omgrf, double omgrf2, const double rvec[3],
+                          EqPoint<NS>& eq, bool check_box) {
+  double ns[NS], gradns[NS][3], ts[NS], gradts[NS][3];
+  int err;
+  if (EQ == RAYS_EQ_SLAB)
+    err = slab_fields<NS>(P, rvec, eq.bvec, eq.gbt, ns, gradns, ts, gradts, check_box);
+  else
+    err = solovev_fields<NS>(P, rvec, eq.bvec, eq.gbt, ns, gradns, ts, gradts, check_box);
+  eq.err = err;
+  // When err != 0 the reference returns with eq undefined (:198-202).  We still fill it (fields
+  // evaluated at the out-of-box point): callers that stop on err never read it, and check_save,
+  // which does read it, then sees defined data (DESIGN.md "defined where the reference is not").
+  const double bmag = sqrt(sq(eq.bvec[0]) + sq(eq.bvec[1]) + sq(eq.bvec[2]));  // :238
+  eq.bmag = bmag;
+#pragma unroll
+  for (int i = 0; i < 3; i++) eq.bunit[i] = eq.bvec[i] / bmag;
+#pragma unroll
+  for (int i = 0; i < 3; i++)  // :244-246
+    eq.gradbmag[i] = eq.gbt[i][0] * eq.bunit[0] + eq.gbt[i][1] * eq.bunit[1] + eq.gbt[i][2] * eq.bunit[2];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++)  // :254-257
+      eq.gradbunit[i][j] = (eq.gbt[i][j] - eq.gradbmag[i] * eq.bunit[j]) / bmag;
+#pragma unroll
+  for (int is = 0; is < NS; is++) {  // :262-265
+    eq.ns[is] = ns[is];
+#pragma unroll
+    for (int i = 0; i < 3; i++) eq.gradns[is][i] = gradns[is][i];
+    const double omgc = P.qs[is] * bmag / P.ms[is];
+    const double omgp2 = ns[is] * P.qs2[is] / P.eps0ms[is];
+    eq.alpha[is] = omgp2 / omgrf2;
+    eq.gamma[is] = omgc / omgrf;
+  }
+  eq.ts0 = ts[0];
+#pragma unroll
+  for (int i = 0; i < 3; i++) eq.gradts0[i] = gradts[0][i];
+}
+
+// deriv_cold                deriv_cold.f90:1-228
+template <int NS>
+RAYS_DEV void deriv_cold(const DevParams& P, const EqPoint<NS>& eq, const double nvec[3],
+                         double dddx[3], double dddk[3], double& dddw) {
+  const double k0 = P.k0;
+  double alpha[NS], gamma[NS];
+#pragma unroll
+  for (int is = 0; is < NS; is++) {
+    alpha[is] = eq.alpha[is];
+    gamma[is] = eq.gamma[is];
+  }
+  const double n3 = nvec[0] * eq.bunit[0] + nvec[1] * eq.bunit[1] + nvec[2] * eq.bunit[2];  // :45
+  double np[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) np[i] = nvec[i] - n3 * eq.bunit[i];
+  const double n1 = sqrt(sq(np[0]) + sq(np[1]) + sq(np[2]));  // :46
+  double dn3dk[3], dn12dk[3], dn3dx[3], dn12dx[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    dn3dk[i] = eq.bunit[i] / k0;              // :50
+    dn12dk[i] = P.two_over_k0 * np[i];        // :51
+    dn3dx[i] = eq.gradbunit[i][0] * nvec[0] + eq.gradbunit[i][1] * nvec[1] + eq.gradbunit[i][2] * nvec[2];
+    dn12dx[i] = -2. * n3 * dn3dx[i];          // :57
+  }
+  double dadx[3][NS], dgdx[3][NS];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int is = 0; is < NS; is++) {
+      dadx[i][is] = eq.alpha[is] * eq.gradns[is][i] / eq.ns[is];  // :64  (0*0/0 = NaN outside plasma)
+      dgdx[i][is] = gamma[is] * eq.gradbmag[i] / eq.bmag;         // :65
+    }
+  const double dn3dw = -n3 / P.omgrf;                // :72
+  const double dn12dw = P.m2_over_omgrf * sq(n1);    // :73
+  double dadw[NS], dgdw[NS];
+#pragma unroll
+  for (int is = 0; is < NS; is++) {
+    dadw[is] = P.m2_over_omgrf * alpha[is];  // :74
+    dgdw[is] = P.m1_over_omgrf * gamma[is];  // :75
+  }
+  double sa = 0.;
+#pragma unroll
+  for (int is = 0; is < NS; is++) sa += alpha[is];
+  const double p = 1. - sa;  // :78
+  double t = 1.;
+#pragma unroll
+  for (int is = 0; is < NS; is++) t *= (1. - sq(gamma[is]));  // :79
+  double dq1da[NS], dq2da[NS];
+#pragma unroll
+  for (int is1 = 0; is1 < NS; is1++) {  // :83-91
+    dq1da[is1] = 1.;
+    dq2da[is1] = 1.;
+#pragma unroll
+    for (int is = 0; is < NS; is++)
+      if (is != is1) {
+        dq1da[is1] = dq1da[is1] * (1. + gamma[is]);
+        dq2da[is1] = dq2da[is1] * (1. - gamma[is]);
+      }
+  }
+  double q1 = 0., q2 = 0., su = 0.;
+#pragma unroll
+  for (int is = 0; is < NS; is++) q1 += alpha[is] * dq1da[is];  // :94
+#pragma unroll
+  for (int is = 0; is < NS; is++) q2 += alpha[is] * dq2da[is];  // :95
+#pragma unroll
+  for (int is = 0; is < NS; is++) su += alpha[is] * dq1da[is] * dq2da[is];
+  const double u = t - su;               // :98
+  const double q = 2. * u - t + q1 * q2; // :101
+  const double n3_2 = sq(n3), n3_4 = pow4(n3), n1_2 = sq(n1), n1_4 = pow4(n1);
+  double duda[NS], dqda[NS], ddda[NS];
+#pragma unroll
+  for (int is = 0; is < NS; is++) {  // :104-112
+    duda[is] = -dq1da[is] * dq2da[is];
+    dqda[is] = 2. * duda[is] + dq1da[is] * q2 + q1 * dq2da[is];
+    ddda[is] = -t * n3_4 + (2. * (u - p * duda[is]) + (-t + duda[is]) * n1_2) * n3_2 - q +
+               p * dqda[is] - (dqda[is] - u + p * duda[is]) * n1_2 + duda[is] * n1_4;
+  }
+  double gp[NS][NS], gm[NS][NS], gpm[NS][NS];
+#pragma unroll
+  for (int is1 = 0; is1 < NS; is1++)
+#pragma unroll
+    for (int is2 = 0; is2 < NS; is2++) {  // :116-125
+      double a = 1., b = 1.;
+#pragma unroll
+      for (int is = 0; is < NS; is++)
+        if (is != is1 && is != is2) {
+          a = a * (1. + gamma[is]);
+          b = b * (1. - gamma[is]);
+        }
+      gp[is1][is2] = a;
+      gm[is1][is2] = b;
+      gpm[is1][is2] = a * b;
+    }
+  double dtdg[NS], dudg[NS], dq1dg[NS], dq2dg[NS], dqdg[NS], dddg[NS];
+#pragma unroll
+  for (int is = 0; is < NS; is++) dtdg[is] = 2. * gamma[is] * duda[is];  // :128
+#pragma unroll
+  for (int is = 0; is < NS; is++) {
+    double a = 0., b = 0., c = 0.;
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+      a += alpha[j] * gpm[j][is];  // :132
+      b += alpha[j] * gp[j][is];   // :138
+      c += alpha[j] * gm[j][is];   // :144
+    }
+    dudg[is] = dtdg[is] + 2. * gamma[is] * (a + alpha[is] * duda[is]);  // :134
+    dq1dg[is] = b - alpha[is] * dq1da[is];                              // :140
+    dq2dg[is] = -c + alpha[is] * dq2da[is];                             // :146
+    dqdg[is] = 2. * dudg[is] - dtdg[is] + dq1dg[is] * q2 + q1 * dq2dg[is];  // :149
+    dddg[is] = dtdg[is] * p * n3_4 + (-2. * p * dudg[is] + (dtdg[is] * p + dudg[is]) * n1_2) * n3_2 +
+               p * dqdg[is] - (dqdg[is] + p * dudg[is]) * n1_2 + dudg[is] * n1_4;  // :152-154
+  }
+  const double dddn3 = (4. * t * p * n3_2 + 2. * (-2. * p * u + (t * p + u) * n1_2)) * n3;  // :157
+  const double dddn12 = (t * p + u) * n3_2 - (q + p * u) + 2. * u * n1_2;                   // :158
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    dddk[i] = dddn3 * dn3dk[i] + dddn12 * dn12dk[i];  // :162
+    double a = 0.;
+#pragma unroll
+    for (int is = 0; is < NS; is++) a += ddda[is] * dadx[i][is] + dddg[is] * dgdx[i][is];  // :166
+    dddx[i] = a + dddn3 * dn3dx[i] + dddn12 * dn12dx[i];                                   // :168
+  }
+  double a = 0.;
+#pragma unroll
+  for (int is = 0; is < NS; is++) a += ddda[is] * dadw[is] + dddg[is] * dgdw[is];
+  dddw = a + dddn3 * dn3dw + dddn12 * dn12dw;  // :171
+}
+
+// Cold dielectric tensor in the Stix frame: the five distinct entries of eps_h
+// (suscep_m.f90:53-86, 142-176) as real numbers.  eps_h(1,1)=eps_h(2,2)=e11 (real),
+// eps_h(3,3)=e33 (real), eps_h(1,2) = i*x12 = -eps_h(2,1) (pure imaginary), rest zero.
+// The reference forms these with complex arithmetic; every dropped term is an exact zero, and
+// chi(1,2) goes through __divdc3 (see divdc3_real), so the values are bit-identical.
+template <int NS>
+RAYS_DEV void eps_cold(const double alpha[NS], const double gamma[NS], double& e11, double& e33,
+                       double& x12) {
+  double s11 = 0., s33 = 0., s12 = 0.;
+#pragma unroll
+  for (int is = 0; is < NS; is++) {
+    const double omg2 = 1. - sq(gamma[is]);
+    s11 = s11 + (-alpha[is] / omg2);                           // suscep_m.f90:72
+    s33 = s33 + (-alpha[is]);                                  // :74
+    s12 = s12 + (-divdc3_real(alpha[is] * gamma[is], omg2));   // :75
+  }
+  e11 = s11 + 1.0;
+  e33 = s33 + 1.0;
+  x12 = s12;
+}
+
+// det(eps_h + nn - n^2 I) for n = (n1, 0, n3): deriv_num.f90:126-134 == check_save.f90:209-218
+RAYS_DEV double epsn_det(double e11, double e33, double x12, double n1, double n3, double nsq) {
+  const double E11 = e11 + n1 * n1 - nsq;
+  const double E22 = e11 + 0. * 0. - nsq;  // n(2)*n(2) = 0
+  const double E33 = e33 + n3 * n3 - nsq;
+  const double E13 = 0. + n1 * n3 - 0. * nsq;
+  // ctmp%re = E33*(E11*E22 - (i x12)(-i x12)... ) - 0 + E31*(0 - E22*E13)
+  return E33 * (E11 * E22 - x12 * x12) - E13 * (E22 * E13);
+}
+
+// determ                    deriv_num.f90:99-153 (ray_dispersion_model == 'cold')
+template <int NS>
+RAYS_DEV double determ(const double bunit[3], const double alpha[NS], const double gamma[NS],
+                       const double kvec[3], double k0) {
+  const double k3 = kvec[0] * bunit[0] + kvec[1] * bunit[1] + kvec[2] * bunit[2];
+  const double k1 = sqrt(sq(kvec[0] - k3 * bunit[0]) + sq(kvec[1] - k3 * bunit[1]) + sq(kvec[2] - k3 * bunit[2]));
+  const double n1 = k1 / k0, n3 = k3 / k0;
+  const double nsq = sq(n1) + 0. + sq(n3);
+  double e11, e33, x12;
+  eps_cold<NS>(alpha, gamma, e11, e33, x12);
+  const double det = epsn_det(e11, e33, x12, n1, n3, nsq);
+  double pr = 1.;
+#pragma unroll
+  for (int is = 0; is < NS; is++) pr *= (1. - sq(gamma[is]));  // :146 (unused species contribute 1)
+  return det * pr;
+}
+
+// Light equilibrium for determ: only bunit, alpha, gamma at a (possibly perturbed) point.
+template <int EQ, int NS>
+RAYS_DEV void eq_for_determ(const DevParams& P, double omgrf, double omgrf2, const double rvec[3],
+                            double bunit[3], double alpha[NS], double gamma[NS]) {
+  EqPoint<NS> e;
+  equilibrium<EQ, NS>(P, omgrf, omgrf2, rvec, e, false);
+#pragma unroll
+  for (int i = 0; i < 3; i++) bunit[i] = e.bunit[i];
+#pragma unroll
+  for (int is = 0; is < NS; is++) {
+    alpha[is] = e.alpha[is];
+    gamma[is] = e.gamma[is];
+  }
+}
+
+// deriv_num                 deriv_num.f90:1-155
+// delta = 1.e-6 (single-precision literal, :37).  Perturbed positions are evaluated without the
+// box test (the reference reads an undefined eq_point there).  Loops over the three axes are kept
+// rolled (selects instead of dynamic register indexing) to bound code size.
+template <int EQ, int NS>
+RAYS_DEV void deriv_num(const DevParams& P, const EqPoint<NS>& eq0, const double rvec0[3],
+                        const double kvec0[3], double dddx[3], double dddk[3], double& dddw) {
+  double bu[3], al[NS], ga[NS];
+#pragma unroll 1
+  for (int i = 0; i < 3; i++) {  // :40-57
+    double rp[3], rm[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      rp[c] = (c == i) ? rvec0[c] + P.delta : rvec0[c];
+      rm[c] = (c == i) ? rvec0[c] - P.delta : rvec0[c];
+    }
+    eq_for_determ<EQ, NS>(P, P.omgrf, P.omgrf2, rp, bu, al, ga);
+    const double det_plus = determ<NS>(bu, al, ga, kvec0, P.k0);
+    eq_for_determ<EQ, NS>(P, P.omgrf, P.omgrf2, rm, bu, al, ga);
+    const double det_minus = determ<NS>(bu, al, ga, kvec0, P.k0);
+    const double d = (det_plus - det_minus) / P.two_delta;
+    if (i == 0) dddx[0] = d;
+    if (i == 1) dddx[1] = d;
+    if (i == 2) dddx[2] = d;
+  }
+#pragma unroll 1
+  for (int i = 0; i < 3; i++) {  // :60-68
+    const double ki = (i == 0) ? kvec0[0] : (i == 1) ? kvec0[1] : kvec0[2];
+    const double change = fmax(P.delta, fabs(P.delta * ki)) / 2.;
+    double kp[3], km[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      kp[c] = (c == i) ? kvec0[c] + change : kvec0[c];
+      km[c] = (c == i) ? kvec0[c] - change : kvec0[c];
+    }
+    const double det_plus = determ<NS>(eq0.bunit, eq0.alpha, eq0.gamma, kp, P.k0);
+    const double det_minus = determ<NS>(eq0.bunit, eq0.alpha, eq0.gamma, km, P.k0);
+    const double d = (det_plus - det_minus) / (2. * change);
+    if (i == 0) dddk[0] = d;
+    if (i == 1) dddk[1] = d;
+    if (i == 2) dddk[2] = d;
+  }
+  // :71-80 omega: per-lane omgrf/k0 instead of rewriting module variables
+  eq_for_determ<EQ, NS>(P, P.omgrf_p, P.omgrf2_p, rvec0, bu, al, ga);
+  const double det_plus = determ<NS>(bu, al, ga, kvec0, P.k0_p);
+  eq_for_determ<EQ, NS>(P, P.omgrf_m, P.omgrf2_m, rvec0, bu, al, ga);
+  const double det_minus = determ<NS>(bu, al, ga, kvec0, P.k0_m);
+  dddw = (det_plus - det_minus) / P.omgrf0_delta;
+}
+
+// ---------------------------------------------------------------------------------------------
+// eqn_ray tail               eqn_ray.f90:131-229: group velocity + ray equations from dD/d(x,k,w).
+// Returns a stop code (0 = ok).  NV = 7 (+5 with integrate_eq_gradients).
+// ---------------------------------------------------------------------------------------------
+template <int NS, int NV>
+RAYS_DEV int ray_equations(const DevParams& P, const EqPoint<NS>& eq, const double dddx[3],
+                           const double dddk[3], double dddw, double dvds[NV]) {
+  if (!(dddw != 0.)) return RAYS_STOP_INFINITE_VG_RHS;  // :133 (`/= 0.` is true for NaN)
+  double vg[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) vg[i] = -dddk[i] / dddw;
+  const double vg0 = sqrt(sq(vg[0]) + sq(vg[1]) + sq(vg[2]));
+  double dsd;
+  if (P.ray_param == RAYS_PARAM_ARCL) {  // :150-170
+    if (dddk[0] != 0. || dddk[1] != 0. || dddk[2] != 0.) {
+      const double sgn = copysign(1.0, dddw);
+      const double nk = sqrt(sq(dddk[0]) + sq(dddk[1]) + sq(dddk[2]));
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        dvds[i] = -sgn * dddk[i] / nk;
+        dvds[3 + i] = sgn * dddx[i] / nk;
+      }
+      dsd = 1.;
+    } else {
+      return RAYS_STOP_RAY_STALLED;
+    }
+  } else {  // 'time' :172-181
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      dvds[i] = vg[i];  // -dddk/dddw
+      dvds[3 + i] = dddx[i] / dddw;
+    }
+    dsd = vg0;
+  }
+  dvds[6] = dsd;  // :190
+  if (NV > 7) {   // :217-229 integrate_eq_gradients
+    double vu[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) vu[i] = vg[i] / vg0;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      dvds[7 + j] = dsd * vu[0] * eq.gbt[0][j] + dsd * vu[1] * eq.gbt[1][j] + dsd * vu[2] * eq.gbt[2][j];
+    dvds[10] = dsd * vu[0] * eq.gradns[0][0] + dsd * vu[1] * eq.gradns[0][1] + dsd * vu[2] * eq.gradns[0][2];
+    dvds[11] = dsd * vu[0] * eq.gradts0[0] + dsd * vu[1] * eq.gradts0[1] + dsd * vu[2] * eq.gradts0[2];
+  }
+  return 0;
+}
+
+// eqn_ray                   eqn_ray.f90:1-236
+template <int EQ, int NS, int DERIV, int NV>
+RAYS_DEV int eqn_ray(const DevParams& P, const double v[NV], double dvds[NV]) {
+  const double rvec[3] = {v[0], v[1], v[2]}, kvec[3] = {v[3], v[4], v[5]};
+  EqPoint<NS> eq;
+  equilibrium<EQ, NS>(P, P.omgrf, P.omgrf2, rvec, eq, true);
+  if (eq.err) return eq.err;  // :90-102
+  double dddx[3], dddk[3], dddw;
+  if (DERIV == RAYS_DERIV_COLD) {
+    const double nvec[3] = {kvec[0] / P.k0, kvec[1] / P.k0, kvec[2] / P.k0};  // :84
+    deriv_cold<NS>(P, eq, nvec, dddx, dddk, dddw);
+  } else {
+    deriv_num<EQ, NS>(P, eq, rvec, kvec, dddx, dddk, dddw);
+  }
+  return ray_equations<NS, NV>(P, eq, dddx, dddk, dddw, dvds);
+}
+
+// ---------------------------------------------------------------------------------------------
+// rhs_eval: ONE evaluation of the ray-equation right-hand side at state v, optionally fused with
+// check_save (check_save.f90:1-237) at the same state.
+//
+// check_save evaluates equilibrium(v) and deriv_cold(eq, v/k0); the next ODE step's first eqn_ray
+// call evaluates the same pure functions at the same v.  Evaluating them once is bit-identical
+// and removes one of the five RHS evaluations per RK4 step.  Keeping a single inlined copy of the
+// RHS (instead of eqn_ray + check_save) also bounds the kernel's code size.
+//   do_check : this evaluation is also a check_save call (per-lane flag; wave-uniform in practice)
+//   resid    : normalised dispersion residual (check_save.f90:163-235)      [do_check only]
+//   cs_flag  : flag check_save latches; cs_stop : stop_ode set by check_save [do_check only]
+//   code     : stop code eqn_ray(v) returns (0 = ok), f = its dvds
+// ---------------------------------------------------------------------------------------------
+template <int EQ, int NS, int DERIV, int NV>
+RAYS_DEV void rhs_eval(const DevParams& P, const double v[NV], bool do_check, double& resid,
+                       int& cs_flag, bool& cs_stop, int& code, double f[NV]) {
+  const double rvec[3] = {v[0], v[1], v[2]}, kvec[3] = {v[3], v[4], v[5]};
+  EqPoint<NS> eq;
+  equilibrium<EQ, NS>(P, P.omgrf, P.omgrf2, rvec, eq, true);
+  const double nvec[3] = {kvec[0] / P.k0, kvec[1] / P.k0, kvec[2] / P.k0};  // eqn_ray.f90:84
+  cs_flag = 0;
+  cs_stop = false;
+  resid = 0.;
+  if (do_check) {
+    cs_flag = eq.err;  // check_save.f90:41-43: flag text only
+    // :53-57
+    const double k3 = kvec[0] * eq.bunit[0] + kvec[1] * eq.bunit[1] + kvec[2] * eq.bunit[2];
+    const double k1 = sqrt(sq(kvec[0] - k3 * eq.bunit[0]) + sq(kvec[1] - k3 * eq.bunit[1]) +
+                           sq(kvec[2] - k3 * eq.bunit[2]));
+    // residual :163-235
+    const double n1 = k1 / P.k0, n3 = k3 / P.k0;
+    const double nsq = sq(n1) + 0. + sq(n3);
+    double e11, e33, x12;
+    eps_cold<NS>(eq.alpha, eq.gamma, e11, e33, x12);
+    const double det = epsn_det(e11, e33, x12, n1, n3, nsq);
+    const double N11 = fabs(e11) + fabs(n1 * n1), N22 = fabs(e11) + fabs(0. * 0.);
+    const double N33 = fabs(e33) + fabs(n3 * n3), N12 = fabs(x12) + fabs(n1 * 0.);
+    const double N13 = 0. + fabs(n1 * n3), N23 = 0. + fabs(0. * n3);
+    const double den = N33 * (N11 * N22) + N33 * (N12 * N12) + N23 * (N11 * N23) + N23 * (N12 * N13) +
+                       N13 * (N12 * N23) + N13 * (N22 * N13);
+    resid = divdc3_real(fabs(det), den);  // eps_norm is complex(rkind) -> __divdc3
+    if (resid > P.resid_limit) {          // :68-71
+      cs_stop = true;
+      cs_flag = RAYS_STOP_DISP_RESIDUAL;
+    }
+  }
+  double dddx[3], dddk[3], dddw;
+  if (DERIV == RAYS_DERIV_COLD || do_check) {
+    deriv_cold<NS>(P, eq, nvec, dddx, dddk, dddw);  // eqn_ray.f90:111 / check_save.f90:82
+    if (do_check && !(fabs(dddw) > 2.2250738585072014e-308)) {  // check_save.f90:90 tiny(dddw)
+      cs_stop = true;
+      cs_flag = RAYS_STOP_INFINITE_VG_CHECK;  // :107-108
+    }
+  }
+  if (DERIV == RAYS_DERIV_NUM) deriv_num<EQ, NS>(P, eq, rvec, kvec, dddx, dddk, dddw);
+  const int rc = ray_equations<NS, NV>(P, eq, dddx, dddk, dddw, f);
+  code = eq.err ? eq.err : rc;  // eqn_ray.f90:90-102 returns before the derivatives
+}
+
+// initialize_ode_vector     initialize_ode_vector.f90:25-54
+template <int EQ, int NS, int NV>
+RAYS_DEV void initialize_ode_vector(const DevParams& P, const double* __restrict__ r0,
+                                    const double* __restrict__ n0, double v[NV]) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    v[i] = r0[i];
+    v[3 + i] = P.k0 * n0[i];
+  }
+  v[6] = 0.;
+  if (NV > 7) {
+    EqPoint<NS> eq;
+    const double rvec[3] = {v[0], v[1], v[2]};
+    equilibrium<EQ, NS>(P, P.omgrf, P.omgrf2, rvec, eq, false);
+    v[7] = eq.bvec[0];
+    v[8] = eq.bvec[1];
+    v[9] = eq.bvec[2];
+    v[10] = eq.ns[0];
+    v[11] = eq.ts0;
+  }
+}
+
+}  // namespace rays

@@ -1,0 +1,52 @@
+// rays_inst.hip -- kernel instantiations.  Compiled once per (solver, equilibrium, derivative)
+// group:  -DRAYS_INST_SOLVER={0,1} -DRAYS_INST_EQ={0,1} -DRAYS_INST_DERIV={0,1}
+// Each group instantiates the species counts NS = 1..6 (nspec = 0..5, species_m.f90:25) and
+// nv = 7 | 12 (integrate_eq_gradients, ode_m.f90:160-173).
+#include "rays_launch.hpp"
+#if RAYS_INST_SOLVER == 0
+#include "rays_rk4.hpp"
+#else
+#include "rays_sg.hpp"
+#endif
+
+#define RAYS_CAT_(a, b, c, d) a##_##b##_##c##_##d
+#define RAYS_CAT(a, b, c, d) RAYS_CAT_(a, b, c, d)
+#define RAYS_STR_(x) #x
+#define RAYS_STR(x) RAYS_STR_(x)
+
+namespace rays {
+
+namespace {
+constexpr int EQ = RAYS_INST_EQ;
+constexpr int DERIV = RAYS_INST_DERIV;
+
+template <int NS, int NV>
+hipError_t launch_one(const DevParams& P, const TraceArgs& A, hipStream_t stream, int* grid_blocks) {
+  constexpr size_t lds = (size_t)(kBlock / kWave) * PointStage<NV, stage_k<NV>()>::kDoublesPerWave * sizeof(double);
+#if RAYS_INST_SOLVER == 0
+  return launch_persistent(rk4_trace_kernel<EQ, NS, DERIV, NV, stage_k<NV>()>, lds, P, A, stream, grid_blocks);
+#else
+  return launch_persistent(sg_trace_kernel<EQ, NS, DERIV, NV, stage_k<NV>()>, lds, P, A, stream, grid_blocks);
+#endif
+}
+
+#if RAYS_INST_SOLVER == 0
+#define RAYS_KNAME "rk4_trace_kernel"
+#else
+#define RAYS_KNAME "sg_trace_kernel"
+#endif
+#define RAYS_ENTRY(NS, NV) \
+  { RAYS_INST_SOLVER, EQ, NS, DERIV, NV, RAYS_KNAME "<" RAYS_STR(RAYS_INST_EQ) ", " #NS ", " RAYS_STR(RAYS_INST_DERIV) ", " #NV ">", &launch_one<NS, NV> }
+
+const KernelEntry kEntries[] = {
+    RAYS_ENTRY(1, 7), RAYS_ENTRY(2, 7), RAYS_ENTRY(3, 7), RAYS_ENTRY(4, 7), RAYS_ENTRY(5, 7), RAYS_ENTRY(6, 7),
+    RAYS_ENTRY(1, 12), RAYS_ENTRY(2, 12), RAYS_ENTRY(3, 12), RAYS_ENTRY(4, 12), RAYS_ENTRY(5, 12), RAYS_ENTRY(6, 12),
+};
+}  // namespace
+
+const KernelEntry* RAYS_CAT(rays_entries, RAYS_INST_SOLVER, RAYS_INST_EQ, RAYS_INST_DERIV)(int* n) {
+  *n = (int)(sizeof(kEntries) / sizeof(kEntries[0]));
+  return kEntries;
+}
+
+}  // namespace rays

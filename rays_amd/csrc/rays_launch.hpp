@@ -1,0 +1,66 @@
+// rays_launch.hpp -- registry of compiled kernel specialisations.
+//
+// The reference dispatches on strings inside the ray loop; here each (solver, equilibrium,
+// species count, derivative model, nv) combination is a separately compiled kernel, instantiated
+// in rays_inst_*.hip (one translation unit per group so they build in parallel) and looked up once
+// per call by rays_capi.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "rays_device.hpp"
+#include "rays_trace.hpp"
+
+namespace rays {
+
+enum { SOLVER_RK4 = 0, SOLVER_SG = 1 };
+
+struct KernelEntry {
+  int solver, eq, ns, deriv, nv;
+  const char* name;
+  // Launches on `stream` with a grid sized for full residency (persistent waves + lane refill).
+  hipError_t (*launch)(const DevParams&, const TraceArgs&, hipStream_t stream, int* grid_blocks);
+};
+
+// Points staged in LDS per lane before a coalesced flush: 8 for nv = 7 (33 KB/wave), 4 for
+// nv = 12 (27 KB/wave), so a 4-wave workgroup stays inside the CU's 160 KB.
+template <int NV>
+constexpr int stage_k() { return NV <= 7 ? 8 : 4; }
+constexpr int kBlock = 256;
+
+template <typename Kernel>
+inline hipError_t launch_persistent(Kernel kernel, size_t lds_bytes, const DevParams& P,
+                                    const TraceArgs& A, hipStream_t stream, int* grid_blocks) {
+  static thread_local int cached_dev = -1;
+  static thread_local int cached_blocks_per_cu = 0, cached_cus = 0;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev != cached_dev) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds_bytes);
+    if (e != hipSuccess) return e;
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return e;
+    cached_blocks_per_cu = per_cu > 0 ? per_cu : 1;
+    cached_cus = prop.multiProcessorCount;
+    cached_dev = dev;
+  }
+  const long long need = ((long long)A.nray + kBlock - 1) / kBlock;
+  long long resident = (long long)cached_blocks_per_cu * cached_cus;
+  int blocks = (int)(need < resident ? need : resident);
+  if (blocks < 1) blocks = 1;
+  if (grid_blocks) *grid_blocks = blocks;
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), lds_bytes, stream, P, A);
+  return hipGetLastError();
+}
+
+// Implemented in rays_inst_*.hip
+const KernelEntry* rk4_entries(int* n);
+const KernelEntry* sg_entries(int* n);
+
+}  // namespace rays

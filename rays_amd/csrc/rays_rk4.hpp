@@ -1,0 +1,195 @@
+// rays_rk4.hpp -- RK4 ray-trace kernel (ode_solver_name = 'RK4_ODE').
+//
+// Reference path restated here:
+//   trace_rays   ray_tracing.f90:67-264   (per-ray bookkeeping, stop logic, recording)
+//   RK4_ode      RK4_ode_m.f90:59-94      (4 stages, early return leaves v untouched)
+//   eqn_ray / check_save                  (rays_device.hpp)
+//
+// Per lane the integrator is a 4-state machine around ONE RHS evaluation per wave-loop trip:
+//   stage 0,1,2 : evaluate f at w (= v + ds*f1/2, v + ds*f2/2, v + ds*f3)  -> f2, f3, f4
+//   stage 3     : w = v + ds*(f1 + 2 f2 + 2 f3 + f4)/6 ; check_save(w) fused with the next step's
+//                 f1 = eqn_ray(w) (same equilibrium + dispersion derivatives, evaluated once)
+// A new ray starts in stage 3 with w = v0 (`first`), which is exactly the reference's initial
+// check_save call (ray_tracing.f90:100) and also yields the first step's f1.
+#pragma once
+
+#include "rays_trace.hpp"
+
+namespace rays {
+
+template <int EQ, int NS, int DERIV, int NV, int K>
+__global__ void __launch_bounds__(256)
+rk4_trace_kernel(const DevParams P, const TraceArgs A) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  PointStage<NV, K> stage;
+  stage.base = lds + wave * PointStage<NV, K>::kDoublesPerWave;
+  stage.lane = lane;
+
+  const unsigned total_lanes = gridDim.x * blockDim.x;
+  const long long npt = (long long)P.nstep_max + 1;
+
+  // ---- per-lane ray state -------------------------------------------------------------------
+  int ray = blockIdx.x * blockDim.x + threadIdx.x;
+  bool alive = ray < A.nray;
+  bool need_init = alive;
+  int j = 3;            // stage
+  bool first = true;    // stage-3 evaluation is the initial check_save
+  int nstep = 0;
+  double s = 0., sout = 0., dsl = 0.;
+  double v[NV], w[NV], acc[NV];
+  double last_resid = 0., prev_resid = 0., maxr = -1.7976931348623157e308;
+  int nbuf = 0;            // points staged in LDS since the last flush
+  long long first_pt = 0;  // global point index of staged slot 0
+#pragma unroll
+  for (int i = 0; i < NV; i++) v[i] = w[i] = acc[i] = 0.;
+
+  while (__any(alive)) {
+    if (need_init) {  // initialize_ode_vector + per-ray resets (ray_tracing.f90:77-93)
+      initialize_ode_vector<EQ, NS, NV>(P, A.rvec0 + 3ll * ray, A.rindex_vec0 + 3ll * ray, v);
+#pragma unroll
+      for (int i = 0; i < NV; i++) w[i] = v[i];
+      j = 3;
+      first = true;
+      nstep = 0;
+      s = 0.;
+      sout = 0.;
+      last_resid = 0.;
+      prev_resid = 0.;
+      maxr = -1.7976931348623157e308;
+      need_init = false;
+    }
+
+    // ---- the one RHS evaluation of this trip -------------------------------------------------
+    double f[NV], resid = 0.;
+    int code = 0, cs_flag = 0;
+    bool cs_stop = false;
+    if (alive) rhs_eval<EQ, NS, DERIV, NV>(P, w, j == 3, resid, cs_flag, cs_stop, code, f);
+
+    // ---- per-lane integrator state machine ---------------------------------------------------
+    int stop = 0;        // 0 = keep going
+    bool done = false;   // ray finished this trip
+    if (alive) {
+      if (j < 3) {
+        if (code) {  // RK4_ode_m.f90:83-89: stage stopped, v untouched
+          stop = code;
+          done = true;
+        } else if (j == 0) {
+#pragma unroll
+          for (int i = 0; i < NV; i++) {
+            acc[i] = acc[i] + 2.0 * f[i];
+            w[i] = v[i] + dsl * f[i] * 0.5;  // (ds*f2)/2.0, exact scaling
+          }
+          j = 1;
+        } else if (j == 1) {
+#pragma unroll
+          for (int i = 0; i < NV; i++) {
+            acc[i] = acc[i] + 2.0 * f[i];
+            w[i] = v[i] + dsl * f[i];
+          }
+          j = 2;
+        } else {
+#pragma unroll
+          for (int i = 0; i < NV; i++) {
+            acc[i] = acc[i] + f[i];
+            w[i] = v[i] + dsl * acc[i] / 6.0;  // RK4_ode_m.f90:91
+          }
+          j = 3;
+        }
+      } else {
+        // stage 3: w is the new state; check_save decides whether the step is recorded
+        if (first) {
+          // ray_tracing.f90:92-112: point 1 = initial state, residual(1) = 0
+          if (nbuf == 0) first_pt = (long long)ray * npt;
+          stage.put(nbuf, v, 0.);
+          nbuf++;
+          if (cs_stop) {  // ray did not start: npoints = 1, summary fields stay zero
+            A.npoints[ray] = 1;
+            A.stop_code[ray] = cs_flag;
+            if (A.end_ray_vec)
+#pragma unroll
+              for (int i = 0; i < NV; i++) A.end_ray_vec[(long long)ray * NV + i] = 0.;
+            if (A.end_residuals) A.end_residuals[ray] = 0.;
+            if (A.max_residuals) A.max_residuals[ray] = 0.;
+            done = true;
+            stop = -1;  // summary already written
+          }
+          first = false;
+        } else {
+#pragma unroll
+          for (int i = 0; i < NV; i++) v[i] = w[i];  // RK4_ode_m.f90:91-92
+          s = sout;
+          if (cs_stop) {  // ray_tracing.f90:214-234: step not recorded, v is the new state
+            stop = cs_flag;
+            done = true;
+          } else {  // :237-243
+            nstep = nstep + 1;
+            if (nbuf == 0) first_pt = (long long)ray * npt + nstep;
+            stage.put(nbuf, v, resid);
+            nbuf++;
+            if (fabs(last_resid) > maxr) maxr = fabs(last_resid);
+            prev_resid = last_resid;
+            last_resid = resid;
+          }
+        }
+        if (!done) {  // top of the next trajectory trip, ray_tracing.f90:118-172
+          s = sout;
+          sout = sout + P.ds;
+          if (sout > P.s_max) {
+            stop = RAYS_STOP_SOUT_GT_SMAX;
+            done = true;
+          } else if (nstep + 1 > P.nstep_max) {
+            stop = RAYS_STOP_NSTEP_MAX;
+            done = true;
+          } else if (code) {  // first RK4 stage of the next step stops (RK4_ode_m.f90:82-83)
+            stop = code;
+            done = true;
+          } else {
+            dsl = sout - s;  // RK4_ode_m.f90:81
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+              acc[i] = f[i];
+              w[i] = v[i] + dsl * f[i] * 0.5;
+            }
+            j = 0;
+          }
+        }
+      }
+      if (done) {
+        if (stop >= 0) {  // ray_tracing.f90:252-260
+          A.npoints[ray] = nstep + 1;
+          A.stop_code[ray] = stop;
+          if (A.end_ray_vec)
+#pragma unroll
+            for (int i = 0; i < NV; i++) A.end_ray_vec[(long long)ray * NV + i] = v[i];
+          if (A.end_residuals) A.end_residuals[ray] = nstep >= 1 ? prev_resid : 0.;
+          if (A.max_residuals) A.max_residuals[ray] = maxr;
+        }
+      }
+    }
+
+    // ---- wave-level: flush staged points, refill finished lanes --------------------------------
+    if (done) {
+      // a finished lane's points must leave LDS before the lane is re-used for another ray:
+      // it drains its own column (once per ray; the coalesced path is the wave flush below)
+      stage.drain_own(A, nbuf, first_pt);
+      nbuf = 0;
+    }
+    if (__any(nbuf == K)) {
+      stage.flush(A, nbuf, first_pt);
+      nbuf = 0;
+    }
+    if (done) {
+      const unsigned nxt = atomicAdd(A.next_ray, 1u) + total_lanes;
+      if (nxt < (unsigned)A.nray) {
+        ray = (int)nxt;
+        need_init = true;
+      } else {
+        alive = false;
+      }
+    }
+  }
+}
+
+}  // namespace rays

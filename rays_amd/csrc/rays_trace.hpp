@@ -1,0 +1,92 @@
+// rays_trace.hpp -- the batched ray launcher shared by the RK4 and SG kernels.
+//
+// Replaces the reference's outer loops (ray_tracing.f90:62-264: OpenMP `parallel do` over rays,
+// sequential `trajectory` loop over output steps) with persistent wave64 workers:
+//
+//   * one ray per lane; the ODE state (v, stage accumulator, next RHS input) lives in VGPRs;
+//   * every trip of the wave loop performs exactly ONE evaluation of the ray-equation RHS for all
+//     live lanes (the expensive, convergent part); the integrator around it is a small per-lane
+//     state machine, so lanes in different stages / different rays never serialise the RHS;
+//   * a lane whose ray terminates pulls the next ray index from a global counter (lane refill),
+//     so a wave stays full while rays of very different length (99..380 steps in the Solovev
+//     fan) are in flight;
+//   * recorded points are staged per wave in LDS (K points x (nv+1) doubles x 64 lanes, rows
+//     padded to 65 doubles) and flushed as contiguous runs of up to K*nv*8 bytes per ray into the
+//     reference layout ray_vec(nv, nstep_max+1, nray) / residual(nstep_max+1, nray)
+//     (ray_results_m.f90:44-46), instead of 64 scattered 56-byte stores per step.
+#pragma once
+
+#include "rays_device.hpp"
+
+namespace rays {
+
+constexpr int kWave = 64;
+constexpr int kRowStride = 65;  // doubles; 65 -> conflict-free b64 column reads at flush
+
+struct TraceArgs {
+  int nray;
+  const double* __restrict__ rvec0;        // [nray][3]
+  const double* __restrict__ rindex_vec0;  // [nray][3]
+  double* __restrict__ ray_vec;            // [nray][nstep_max+1][nv]
+  double* __restrict__ residual;           // [nray][nstep_max+1]
+  int* __restrict__ npoints;               // [nray]
+  int* __restrict__ stop_code;             // [nray]
+  double* __restrict__ end_ray_vec;        // [nray][nv]      (may be null)
+  double* __restrict__ end_residuals;      // [nray]          (may be null)
+  double* __restrict__ max_residuals;      // [nray]          (may be null)
+  unsigned int* __restrict__ next_ray;     // refill counter, zeroed before launch
+};
+
+// Per-wave LDS staging of recorded trajectory points.
+template <int NV, int K>
+struct PointStage {
+  static constexpr int kRows = K * (NV + 1);
+  static constexpr int kDoublesPerWave = kRows * kRowStride;
+  double* base;  // this wave's region
+  int lane;
+
+  RAYS_DEV void put(int slot, const double v[NV], double resid) {
+    double* p = base + (slot * (NV + 1)) * kRowStride + lane;
+#pragma unroll
+    for (int c = 0; c < NV; c++) p[c * kRowStride] = v[c];
+    p[NV * kRowStride] = resid;
+  }
+
+  // One lane writes out its own staged points (ray termination).
+  RAYS_DEV void drain_own(const TraceArgs& A, int nbuf, long long first_pt) {
+    for (int k = 0; k < nbuf; k++) {
+      const double* p = base + (k * (NV + 1)) * kRowStride + lane;
+#pragma unroll
+      for (int c = 0; c < NV; c++) A.ray_vec[(first_pt + k) * NV + c] = p[c * kRowStride];
+      A.residual[first_pt + k] = p[NV * kRowStride];
+    }
+  }
+
+  // All 64 lanes call this together.  nbuf = points this lane has staged, first_pt = global point
+  // index (ray*(nstep_max+1) + step) of its slot 0.
+  RAYS_DEV void flush(const TraceArgs& A, int nbuf, long long first_pt) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int r = 0; r < kWave; r++) {
+      const int n = __builtin_amdgcn_readlane(nbuf, r);
+      if (n == 0) continue;
+      const unsigned lo = __builtin_amdgcn_readlane((unsigned)(first_pt & 0xffffffffll), r);
+      const unsigned hi = __builtin_amdgcn_readlane((unsigned)((unsigned long long)first_pt >> 32), r);
+      const long long pt0 = (long long)(((unsigned long long)hi << 32) | lo);
+      const int total = n * (NV + 1);
+      for (int e = lane; e < total; e += kWave) {
+        const int k = e / (NV + 1), c = e - k * (NV + 1);
+        const double val = base[e * kRowStride + r];
+        if (c < NV)
+          A.ray_vec[(pt0 + k) * NV + c] = val;
+        else
+          A.residual[pt0 + k] = val;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+};
+
+}  // namespace rays

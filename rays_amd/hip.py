@@ -1,0 +1,139 @@
+"""ctypes binding of the C ABI in include/rays_hip.h (librays_hip.so).
+
+This is the only compute path of the package: if the HIP library is missing or no GPU is
+visible the calls raise -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .params import RaysParams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librays_hip.so")
+
+# every symbol include/rays_hip.h declares
+EXPORTED_SYMBOLS = (
+    "rays_hip_init", "rays_hip_finalize", "rays_hip_device_count", "rays_hip_last_error",
+    "rays_hip_stop_flag_text", "rays_hip_check_params", "rays_hip_trace", "rays_hip_trace_device",
+    "rays_hip_kernel_name", "rays_hip_probe",
+)
+
+_lib = None
+
+
+class RaysHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load librays_hip.so (built by `make -C rays_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RaysHipError(
+            f"{LIB_PATH} not found: build it with `make -C rays_amd/csrc` (needs hipcc, gfx950). "
+            "rays_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
+    pp = C.POINTER(RaysParams)
+    lib.rays_hip_init.restype = C.c_int
+    lib.rays_hip_init.argtypes = [C.c_int]
+    lib.rays_hip_finalize.restype = C.c_int
+    lib.rays_hip_device_count.restype = C.c_int
+    lib.rays_hip_last_error.restype = C.c_int
+    lib.rays_hip_last_error.argtypes = [C.c_char_p, C.c_int]
+    lib.rays_hip_stop_flag_text.restype = C.c_char_p
+    lib.rays_hip_stop_flag_text.argtypes = [C.c_int]
+    lib.rays_hip_check_params.restype = C.c_int
+    lib.rays_hip_check_params.argtypes = [pp]
+    lib.rays_hip_kernel_name.restype = C.c_char_p
+    lib.rays_hip_kernel_name.argtypes = [pp]
+    lib.rays_hip_trace.restype = C.c_int
+    lib.rays_hip_trace.argtypes = [pp, C.c_int, dp, dp, dp, dp, ip, ip, dp, dp, dp, dp]
+    lib.rays_hip_trace_device.restype = C.c_int
+    lib.rays_hip_trace_device.argtypes = [pp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
+    lib.rays_hip_probe.restype = C.c_int
+    lib.rays_hip_probe.argtypes = [pp, C.c_int, dp, dp, dp, dp, dp, ip]
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(1024)
+    load().rays_hip_last_error(buf, 1024)
+    return buf.value.decode(errors="replace")
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RaysHipError(f"{what} failed (rc={rc}): {last_error()}")
+
+
+def stop_flag_text(code: int) -> str:
+    return load().rays_hip_stop_flag_text(int(code)).decode()
+
+
+def check_params(p: RaysParams):
+    _check(load().rays_hip_check_params(C.byref(p)), "rays_hip_check_params")
+
+
+def kernel_name(p: RaysParams) -> str:
+    return load().rays_hip_kernel_name(C.byref(p)).decode()
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def trace_host(p: RaysParams, rvec0, rindex_vec0, ngpu: int = 0) -> dict:
+    """rays_hip_trace: host numpy arrays in / out (the Fortran drop-in entry)."""
+    lib = load()
+    rvec0 = np.ascontiguousarray(rvec0, dtype=np.float64)
+    rindex_vec0 = np.ascontiguousarray(rindex_vec0, dtype=np.float64)
+    nray, nv, npt = len(rvec0), p.nv, p.nstep_max + 1
+    if lib.rays_hip_init(int(ngpu)) < 0:
+        raise RaysHipError("rays_hip_init: " + last_error())
+    out = dict(
+        ray_vec=np.zeros((nray, npt, nv)), residual=np.zeros((nray, npt)),
+        npoints=np.zeros(nray, dtype=np.int32), stop_code=np.zeros(nray, dtype=np.int32),
+        end_ray_vec=np.zeros((nray, nv)), end_residuals=np.zeros(nray), max_residuals=np.zeros(nray))
+    el = C.c_double(0.0)
+    rc = lib.rays_hip_trace(C.byref(p), nray, _dp(rvec0), _dp(rindex_vec0), _dp(out["ray_vec"]),
+                            _dp(out["residual"]), _ip(out["npoints"]), _ip(out["stop_code"]),
+                            _dp(out["end_ray_vec"]), _dp(out["end_residuals"]),
+                            _dp(out["max_residuals"]), C.byref(el))
+    _check(rc, "rays_hip_trace")
+    out["elapsed_s"] = el.value
+    return out
+
+
+def trace_device(p: RaysParams, nray: int, d_rvec0: int, d_rindex_vec0: int, d_ray_vec: int,
+                 d_residual: int, d_npoints: int, d_stop_code: int, d_end_ray_vec: int = 0,
+                 d_end_residuals: int = 0, d_max_residuals: int = 0, stream: int = 0,
+                 zero_fill: bool = True):
+    """rays_hip_trace_device: raw device pointers (ints), asynchronous on `stream`."""
+    rc = load().rays_hip_trace_device(
+        C.byref(p), int(nray), d_rvec0, d_rindex_vec0, d_ray_vec, d_residual, d_npoints, d_stop_code,
+        d_end_ray_vec or None, d_end_residuals or None, d_max_residuals or None, stream or None,
+        0 if zero_fill else 1)
+    _check(rc, "rays_hip_trace_device")
+
+
+def probe(p: RaysParams, v) -> dict:
+    v = np.ascontiguousarray(v, dtype=np.float64).reshape(-1, p.nv)
+    n = len(v)
+    cold, num = np.zeros((n, 7)), np.zeros((n, 7))
+    dvds, resid, codes = np.zeros((n, p.nv)), np.zeros(n), np.zeros((n, 4), dtype=np.int32)
+    rc = load().rays_hip_probe(C.byref(p), n, _dp(v), _dp(cold), _dp(num), _dp(dvds), _dp(resid),
+                               _ip(codes))
+    _check(rc, "rays_hip_probe")
+    return dict(cold=cold, num=num, dvds=dvds, resid=resid, codes=codes)

@@ -1,0 +1,54 @@
+"""Shared helpers for the parity tests."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from rays_amd.namelist import read_namelist
+from rays_amd.params import STOP_CODE, params_from_namelist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+GOLDEN_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_num",
+                "gold_solovev64_sg_cold", "gold_solovev64_sg_num"]
+
+
+def load_golden(name):
+    g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"), allow_pickle=False)
+    nml = read_namelist(os.path.join(ROOT, "configs", str(g["config"])))
+    return g, nml, params_from_namelist(nml)
+
+
+def stop_codes(flags):
+    return np.array([STOP_CODE[str(f)] for f in flags], dtype=np.int32)
+
+
+def assert_matches_golden(out, g, p, rel_tol=1e-10, resid_atol=1e-12, exact=False):
+    """Parity bar (BASELINE.json north_star): exact ray counts / step indices / stop flags,
+    trajectories within 1e-10 relative per step (norm-wise on r and k);
+    residual with an absolute tolerance (it is a cancellation remainder)."""
+    np.testing.assert_array_equal(out["npoints"], g["npoints"])
+    np.testing.assert_array_equal(out["stop_code"], stop_codes(g["stop_flag"]))
+    keep = g["ray_vec"].shape[1]
+    rv, ref = out["ray_vec"][:, :keep, :], g["ray_vec"]
+    assert not out["ray_vec"][:, keep:, :].any()
+    if exact:
+        np.testing.assert_array_equal(rv, ref)
+        np.testing.assert_array_equal(out["residual"][:, :keep], g["residual"])
+        np.testing.assert_array_equal(out["end_ray_vec"], g["end_ray_vec"])
+        return 0.0
+    worst = 0.0
+    for sl in (slice(0, 3), slice(3, 6)):
+        num = np.linalg.norm(rv[..., sl] - ref[..., sl], axis=-1)
+        den = np.linalg.norm(ref[..., sl], axis=-1)
+        mask = den > 0
+        worst = max(worst, float((num[mask] / den[mask]).max()))
+    assert worst <= rel_tol, f"trajectory rel err {worst:.3e} > {rel_tol}"
+    d7 = np.abs(rv[..., 6] - ref[..., 6])
+    assert (d7 <= rel_tol * np.maximum(np.abs(ref[..., 6]), 1e-30) + 1e-300).all()
+    np.testing.assert_allclose(out["residual"][:, :keep], g["residual"], rtol=0, atol=resid_atol)
+    # zero beyond npoints (ray_results_m.f90:154-164)
+    for r, n in enumerate(g["npoints"]):
+        assert not out["ray_vec"][r, n:, :].any() and not out["residual"][r, n:].any()
+    return worst

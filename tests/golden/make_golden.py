@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the REFERENCE binary.
+
+Runs oracle/_ref/rays_ref_dump (the reference RAYS_project hot path compiled from
+/root/reference by oracle/build_ref.sh, amdflang -O2 -ffp-contract=off) on the namelists in
+configs/, and cuts small fixtures (inputs + expected outputs, data only) from its raw dump.
+Only runs where /root/reference was available to build the binary; the committed .npz files are
+what the tests read.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from tests.refdump import read_dump  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "rays_ref_dump")
+
+# (fixture name, config, ray subset (None = all), probe stride, n probes kept)
+CASES = [
+    ("cfg1_slab16_rk4", "cfg1_slab16_rk4.in", None, 25, 200),
+    ("cfg2_solovev1024_rk4", "cfg2_solovev1024_rk4.in", list(range(0, 1024, 33)) + [1023], 40, 400),
+    ("gold_solovev64_sg_cold", "gold_solovev64_sg_cold.in", list(range(0, 64, 5)), 0, 0),
+    ("gold_solovev64_sg_num", "gold_solovev64_sg_num.in", list(range(0, 64, 5)), 0, 0),
+    ("gold_solovev64_rk4_num", "gold_solovev64_rk4_num.in", list(range(0, 64, 5)), 0, 0),
+]
+
+
+def main():
+    if not os.path.exists(REF):
+        sys.exit("oracle/_ref/rays_ref_dump missing: run `bash oracle/build_ref.sh` first")
+    for name, cfg, subset, stride, nprobe in CASES:
+        with tempfile.TemporaryDirectory() as d:
+            shutil.copy(os.path.join(ROOT, "configs", cfg), os.path.join(d, "rays.in"))
+            env = dict(os.environ, RAYS_DUMP_FILE="dump.bin", RAYS_DUMP_PROBE=str(stride))
+            subprocess.run([REF], cwd=d, env=env, check=True, stdout=subprocess.DEVNULL)
+            ref = read_dump(os.path.join(d, "dump.bin"))
+        idx = np.arange(ref["nray"]) if subset is None else np.array(subset)
+        npts = ref["npoints"][idx]
+        keep = int(npts.max())
+        out = dict(
+            config=np.array(cfg), ray_index=idx.astype(np.int32), nray_full=np.int32(ref["nray"]),
+            npoints_full=ref["npoints"].astype(np.int32),
+            stop_flag_full=np.array(ref["stop_flag"]),
+            rvec0=ref["rvec0"][idx], rindex_vec0=ref["rindex_vec0"][idx],
+            rvec0_full=ref["rvec0"], rindex_vec0_full=ref["rindex_vec0"],
+            npoints=npts.astype(np.int32), stop_flag=np.array([ref["stop_flag"][i] for i in idx]),
+            ray_vec=ref["ray_vec"][idx, :keep, :].copy(), residual=ref["residual"][idx, :keep].copy(),
+            end_ray_vec=ref["end_ray_vec"][idx],
+            consts=np.array([ref[k] for k in ("omgrf", "k0", "clight", "eps0")]),
+            qs=ref["qs"], ms=ref["ms"], n0s=ref["n0s"], t0s=ref["t0s"],
+            psiB=np.float64(ref["solovev"]["psiB"]),
+        )
+        # beyond npoints the reference arrays are zero (ray_results_m.f90:154-164)
+        for r, n in enumerate(npts):
+            assert not ref["ray_vec"][idx[r], n:, :].any() and not ref["residual"][idx[r], n:].any()
+        if stride and "probes" in ref:
+            pr = ref["probes"]
+            sel = np.linspace(0, len(pr) - 1, min(nprobe, len(pr))).astype(int)
+            out["probes"] = pr[sel]
+        path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: nray={ref['nray']} kept={len(idx)} maxpts={keep} "
+              f"steps={int((ref['npoints'] - 1).sum())} -> {os.path.getsize(path) / 1e3:.0f} kB")
+
+
+if __name__ == "__main__":
+    main()

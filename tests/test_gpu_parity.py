@@ -1,0 +1,55 @@
+"""GPU parity tests proper: HIP path (through the C ABI) vs the reference golden vectors and vs
+the CPU oracle on the same inputs."""
+import numpy as np
+import pytest
+
+from rays_amd import hip
+from tests import oracle_lib
+from tests.common import GOLDEN_CASES, assert_matches_golden, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RK4_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_num"]
+
+
+@pytest.mark.parametrize("name", RK4_CASES)
+def test_rk4_matches_reference_golden(name):
+    g, nml, p = load_golden(name)
+    out = hip.trace_host(p, g["rvec0"], g["rindex_vec0"], ngpu=1)
+    worst = assert_matches_golden(out, g, p)
+    print(f"{name}: worst rel err vs reference {worst:.3e}")
+
+
+@pytest.mark.parametrize("name", ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4"])
+def test_device_functions_match_reference_probes(name):
+    g, nml, p = load_golden(name)
+    pr = g["probes"]
+    dev = hip.probe(p, pr["v"])
+    for key in ("cold", "num", "dvds"):
+        ref = pr[key]
+        err = np.abs(dev[key] - ref) / np.maximum(np.abs(ref), 1e-300)
+        err = np.where(np.isnan(ref) & np.isnan(dev[key]), 0.0, err)
+        assert np.nanmax(err) < 1e-9 if key == "num" else np.nanmax(err) < 1e-12, (key, np.nanmax(err))
+        print(name, key, "bitwise" if np.array_equal(dev[key], ref, equal_nan=True) else f"max rel {np.nanmax(err):.2e}")
+    both_nan = np.isnan(pr["resid"]) & np.isnan(dev["resid"])
+    assert (both_nan | (np.abs(dev["resid"] - pr["resid"]) <= 1e-12)).all()
+
+
+def test_full_fan_matches_oracle():
+    """Full cfg2 fan (1024 rays): exact counts/flags vs the reference, values vs the oracle."""
+    g, nml, p = load_golden("cfg2_solovev1024_rk4")
+    out = hip.trace_host(p, g["rvec0_full"], g["rindex_vec0_full"], ngpu=1)
+    np.testing.assert_array_equal(out["npoints"], g["npoints_full"])
+    ora = oracle_lib.trace(p, g["rvec0_full"], g["rindex_vec0_full"])
+    np.testing.assert_array_equal(out["npoints"], ora["npoints"])
+    np.testing.assert_array_equal(out["stop_code"], ora["stop_code"])
+    d = np.abs(out["ray_vec"] - ora["ray_vec"])
+    scale = np.maximum(np.abs(ora["ray_vec"]), 1e-30)
+    print("cfg2 full fan: bitwise" if np.array_equal(out["ray_vec"], ora["ray_vec"]) else
+          f"cfg2 full fan: max abs diff {d.max():.3e}")
+    rel = np.linalg.norm(out["ray_vec"][..., :3] - ora["ray_vec"][..., :3], axis=-1) / \
+        np.maximum(np.linalg.norm(ora["ray_vec"][..., :3], axis=-1), 1e-30)
+    assert rel.max() < 1e-10
+    np.testing.assert_allclose(out["end_ray_vec"], ora["end_ray_vec"], rtol=1e-10, atol=0, equal_nan=True)
+    np.testing.assert_allclose(out["end_residuals"], ora["end_residuals"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(out["max_residuals"], ora["max_residuals"], rtol=0, atol=1e-12)
