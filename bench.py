@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the RAYS hot path on MI355X.
+
+Metric (BASELINE.json): recorded ray-steps/sec, whole job, on the 64k-ray Solovev fan
+(configs/cfg3b_solovev64k_rk4.in: 256 x 256 n_theta x n_phi fan, RK4_ODE, cold-plasma dD).
+
+A "step" of the bench = ONE pass of the hot path over the fan: the trace kernel over all rays of
+this rank (inputs resident in HBM), plus -- for N > 1 -- the RCCL gather of the trajectories to
+rank 0.  Output arrays are zero-filled once before the timed region, exactly as the reference does
+in initialize_ray_results_m (ray_results_m.f90:154-164), not inside trace_rays.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config configs/....in]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1 is weak scaling: the fan grows to 256*N x 256 rays over the same launch-angle range and is
+block-partitioned, 65536 contiguous rays per rank (the reference's `schedule(static)`).
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def build_fan(cfg_path, world):
+    from rays_amd.namelist import read_namelist
+    from rays_amd.params import params_from_namelist
+    from rays_amd.ray_init import initialize_ray_init
+
+    nml = read_namelist(cfg_path)
+    if world > 1:  # weak scaling: world x more launch angles in n_theta over the same range
+        g = nml["solovev_ray_init_nphi_ktheta_list"] if "solovev_ray_init_nphi_ktheta_list" in nml \
+            else nml["simple_slab_ray_init_list"]
+        if "n_rindex_theta" in g:
+            g["n_rindex_theta"] = int(g["n_rindex_theta"]) * world
+            g["delta_rindex_theta"] = float(g["delta_rindex_theta"]) / world
+        else:
+            g["n_ky_launch"] = int(g["n_ky_launch"]) * world
+            g["delta_rindex_y0"] = float(g.get("delta_rindex_y0", 0.0)) / world
+        nml["ray_init_list"]["nray_max"] = int(nml["ray_init_list"]["nray_max"]) * world
+    p = params_from_namelist(nml)
+    r0, n0, _ = initialize_ray_init(p, nml)
+    return nml, p, r0, n0
+
+
+def cpu_baseline(cfg_path, budget_s=25.0):
+    """Reference CPU path on this host's cores, on a bounded sample of the same fan.
+
+    kind "reference": oracle/_ref/rays_ref_dump (the reference RAYS_project hot path compiled from
+    its own sources) run on the fan subsampled 4x4 in launch angle (4096 rays), timing trace_rays
+    only.  Falls back to the C restatement (kind "port") if the binary is not there."""
+    from rays_amd.namelist import read_namelist
+
+    cores = os.cpu_count() or 1
+    ref = os.path.join(ROOT, "oracle", "_ref", "rays_ref_dump")
+    text = open(cfg_path).read()
+    nml = read_namelist(cfg_path)
+    sub = 4
+    import re
+
+    def scale(txt, key_n, key_d):
+        n = int(re.search(key_n + r"\s*=\s*(\d+)", txt).group(1))
+        d = float(re.search(key_d + r"\s*=\s*([-\d.eE+]+)", txt).group(1))
+        txt = re.sub(key_n + r"\s*=\s*\d+", f"{key_n} = {max(1, n // sub)}", txt)
+        txt = re.sub(key_d + r"\s*=\s*[-\d.eE+]+", f"{key_d} = {d * sub!r}", txt)
+        return txt
+
+    if "solovev_ray_init_nphi_ktheta_list" in nml:
+        text = scale(text, "n_rindex_theta", "delta_rindex_theta")
+        text = scale(text, "n_rindex_phi", "delta_rindex_phi")
+        sample = "same Solovev fan subsampled 4x4 in launch angle (64x64 = 4096 rays), all steps"
+    else:
+        text = scale(text, "n_ky_launch", "delta_rindex_y0")
+        text = scale(text, "n_kz_launch", "delta_rindex_z0")
+        sample = "same slab fan subsampled 4x4 in launch index"
+    if os.path.exists(ref):
+        with tempfile.TemporaryDirectory() as d:
+            open(os.path.join(d, "rays.in"), "w").write(text)
+            env = dict(os.environ, RAYS_DUMP_FILE="none")
+            try:
+                out = subprocess.run([ref], cwd=d, env=env, capture_output=True, text=True,
+                                     timeout=600).stdout
+                vals = dict(l.split("=")[0].split()[-1:] + [l.split("=")[1].strip()]
+                            for l in out.splitlines() if l.startswith("RAYS_REF"))
+                return dict(value=float(vals["steps_per_s"]), unit="ray-steps/s",
+                            cores=int(vals["threads"]), kind="reference",
+                            sample=sample + f"; {vals['total_steps']} steps in {float(vals['trace_wall_s']):.2f} s, "
+                            "reference RAYS_project trace_rays (amdflang -O2 -fopenmp), OpenMP over rays")
+            except Exception as e:  # fall through to the port
+                print(f"[bench] reference CPU baseline failed: {e}", file=sys.stderr)
+    from tests import oracle_lib
+    from rays_amd.params import params_from_namelist
+    from rays_amd.namelist import parse_namelist
+    from rays_amd.ray_init import initialize_ray_init
+
+    nml2 = parse_namelist(text)
+    p = params_from_namelist(nml2)
+    r0, n0, _ = initialize_ray_init(p, nml2)
+    t0 = time.perf_counter()
+    o = oracle_lib.trace(p, r0, n0, nthreads=cores)
+    dt = time.perf_counter() - t0
+    steps = int(np.maximum(o["npoints"].astype(np.int64) - 1, 0).sum())
+    return dict(value=steps / dt, unit="ray-steps/s", cores=cores, kind="port",
+                sample=sample + f"; {steps} steps in {dt:.2f} s, C restatement (oracle/), OpenMP over rays")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=os.path.join(ROOT, "configs", "cfg3b_solovev64k_rk4.in"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the trajectory gather (diagnostic)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from rays_amd import hip
+    from rays_amd.trace import DeviceTrace
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    nml, p, r0, n0 = build_fan(args.config, world)
+    nray_total = len(r0)
+    per = (nray_total + world - 1) // world
+    lo, hi = min(nray_total, rank * per), min(nray_total, (rank + 1) * per)
+    tr = DeviceTrace(p, r0[lo:hi], n0[lo:hi], device=dev)
+    nv, npt = p.nv, p.nstep_max + 1
+
+    # first pass (also the zero-fill, as initialize_ray_results_m does) + workload size
+    tr.launch(zero_fill=True)
+    torch.cuda.synchronize()
+    npts_local = tr.npoints.to(torch.int64)
+    steps_local = int(torch.clamp(npts_local - 1, min=0).sum().item())
+    points_local = int(npts_local.sum().item())
+
+    # ---- multi-GPU exchange state: compact (CSR) trajectories, grouped send/recv to rank 0 ----
+    gather = None
+    if world > 1 and not args.no_gather:
+        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([points_local], dtype=torch.int64, device=dev))
+        counts = [int(c.item()) for c in counts]
+        nrays = [min(nray_total, (r + 1) * per) - min(nray_total, r * per) for r in range(world)]
+        offsets = torch.zeros(hi - lo, dtype=torch.int64, device=dev)
+        packed_vec = torch.empty((max(points_local, 1), nv), dtype=torch.float64, device=dev)
+        packed_res = torch.empty(max(points_local, 1), dtype=torch.float64, device=dev)
+        if rank == 0:
+            g_ray_vec = torch.zeros((nray_total, npt, nv), dtype=torch.float64, device=dev)
+            g_residual = torch.zeros((nray_total, npt), dtype=torch.float64, device=dev)
+            g_npoints = [torch.zeros(n, dtype=torch.int32, device=dev) for n in nrays]
+            g_stop = [torch.zeros(n, dtype=torch.int32, device=dev) for n in nrays]
+            r_vec = [None] + [torch.empty((max(c, 1), nv), dtype=torch.float64, device=dev) for c in counts[1:]]
+            r_res = [None] + [torch.empty(max(c, 1), dtype=torch.float64, device=dev) for c in counts[1:]]
+            r_off = [torch.zeros(n, dtype=torch.int64, device=dev) for n in nrays]
+
+        def gather():
+            stream = torch.cuda.current_stream().cuda_stream
+            torch.cumsum(tr.npoints, 0, dtype=torch.int64, out=offsets)
+            offsets.sub_(tr.npoints)  # exclusive prefix
+            hip.pack_device(hi - lo, nv, p.nstep_max, tr.npoints.data_ptr(), offsets.data_ptr(),
+                            tr.ray_vec.data_ptr(), tr.residual.data_ptr(), packed_vec.data_ptr(),
+                            packed_res.data_ptr(), stream)
+            if rank == 0:
+                ops = []
+                for r in range(1, world):
+                    ops += [dist.P2POp(dist.irecv, g_npoints[r], r), dist.P2POp(dist.irecv, g_stop[r], r),
+                            dist.P2POp(dist.irecv, r_vec[r], r), dist.P2POp(dist.irecv, r_res[r], r)]
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+                # own slab is already padded: copy; peers: unpack into their slab of the global arrays
+                g_ray_vec[0:nrays[0]].copy_(tr.ray_vec)
+                g_residual[0:nrays[0]].copy_(tr.residual)
+                for r in range(1, world):
+                    torch.cumsum(g_npoints[r], 0, dtype=torch.int64, out=r_off[r])
+                    r_off[r].sub_(g_npoints[r])
+                    b = min(nray_total, r * per)
+                    hip.unpack_device(nrays[r], nv, p.nstep_max, g_npoints[r].data_ptr(), r_off[r].data_ptr(),
+                                      r_vec[r].data_ptr(), r_res[r].data_ptr(),
+                                      g_ray_vec[b:b + nrays[r]].data_ptr(), g_residual[b:b + nrays[r]].data_ptr(),
+                                      stream)
+            else:
+                ops = [dist.P2POp(dist.isend, tr.npoints, 0), dist.P2POp(dist.isend, tr.stop_code, 0),
+                       dist.P2POp(dist.isend, packed_vec, 0), dist.P2POp(dist.isend, packed_res, 0)]
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        tr.launch(zero_fill=False)
+        if ev is not None:
+            ev[1].record()
+        if gather is not None:
+            gather()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([steps_local], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed = float(tmax.item())
+    total_steps = int(tot.item())
+
+    # the timed passes must have reproduced the first pass (deterministic kernels)
+    assert int(torch.clamp(tr.npoints.to(torch.int64) - 1, min=0).sum().item()) == steps_local
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = total_steps / (elapsed / args.steps)
+        bytes_per_launch = 8.0 * (nv + 1) * steps_local  # 8*(nv+1) B per recorded step
+        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                t = json.load(open(tpath))
+                if t.get("config") == os.path.basename(args.config):
+                    traffic = t.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        line = {
+            "metric": "ray-steps/sec (whole node), 64k-ray Solovev fan",
+            "value": value, "unit": "ray-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": os.path.basename(args.config),
+                       "rays_per_gpu": hi - lo, "rays_total": nray_total,
+                       "recorded_steps_per_pass": total_steps, "nstep_max": p.nstep_max,
+                       "ode": "RK4_ODE" if p.ode_solver == 0 else "SG_ODE",
+                       "deriv": "cold" if p.ray_deriv == 0 else "numerical",
+                       "kernel": hip.kernel_name(p),
+                       "exchange": ("none" if world == 1 else
+                                    ("skipped" if args.no_gather else "packed send/recv to rank 0 (RCCL)"))},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "note": "FP64-VALU/latency bound path: 64 B written per ~3 kflop step (DESIGN.md)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.config)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -178,6 +178,20 @@ int rays_hip_trace_device(const rays_params_t* p, int nray,
  * scripts: matches the rocprofv3 kernel-trace name prefix). */
 const char* rays_hip_kernel_name(const rays_params_t* p);
 
+/* ---- multi-GPU trajectory exchange helpers ---------------------------------
+ * The padded reference layout is mostly zeros (a ray uses npoints of nstep_max+1 slots).  Before
+ * the RCCL gather a rank packs its slab to packed_vec[sum(npoints)][nv], packed_res[sum(npoints)]
+ * (d_offsets = exclusive prefix sum of npoints, int64); the root unpacks a peer's block into its
+ * slab of the padded global arrays (which must be zero-filled beforehand).  Device pointers,
+ * asynchronous on hip_stream. */
+int rays_hip_pack_device(int nray, int nv, int nstep_max, const int32_t* d_npoints,
+                         const int64_t* d_offsets, const double* d_ray_vec, const double* d_residual,
+                         double* d_packed_vec, double* d_packed_res, void* hip_stream);
+int rays_hip_unpack_device(int nray, int nv, int nstep_max, const int32_t* d_npoints,
+                           const int64_t* d_offsets, const double* d_packed_vec,
+                           const double* d_packed_res, double* d_ray_vec, double* d_residual,
+                           void* hip_stream);
+
 /* Diagnostic entry used by the parity tests: evaluates equilibrium + deriv_cold + deriv_num +
  * eqn_ray + check_save at n states on the current device (host pointers; nv must be 7, nspec 1|2).
  * cold7/num7[n][7] = dddx(3) dddk(3) dddw; dvds[n][7]; resid[n]; codes[n][4] = equilibrium err,

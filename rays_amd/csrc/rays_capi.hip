@@ -27,6 +27,9 @@ RAYS_DECL_ENTRIES(1, 0, 0)
 RAYS_DECL_ENTRIES(1, 0, 1)
 RAYS_DECL_ENTRIES(1, 1, 0)
 RAYS_DECL_ENTRIES(1, 1, 1)
+hipError_t launch_pack(bool pack, int nray, int nv, int nstep_max, const int32_t* npoints,
+                       const long long* offsets, double* ray_vec, double* residual, double* packed_vec,
+                       double* packed_res, hipStream_t stream);
 __global__ void probe_kernel(const DevParams P, int eq, int ns, int nv, int n, const double* v,
                              double* cold7, double* num7, double* dvds, double* resid, int* codes);
 }  // namespace rays
@@ -235,8 +238,8 @@ int rays_hip_finalize(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (size_t d = 0; d < g_ws.size(); d++)
     if (g_ws[d].counters) {
-      hipSetDevice((int)d);
-      hipFree(g_ws[d].counters);
+      (void)hipSetDevice((int)d);
+      (void)hipFree(g_ws[d].counters);
       g_ws[d].counters = nullptr;
     }
   g_devices.clear();
@@ -382,9 +385,9 @@ static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1
     if (max_residuals) DEV_CHK(hipMemcpyAsync(max_residuals + r0, d_mr, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     DEV_CHK(hipStreamSynchronize(st));
   } while (0);
-  hipFree(d_r); hipFree(d_n); hipFree(d_rv); hipFree(d_res); hipFree(d_np); hipFree(d_sc);
-  hipFree(d_ev); hipFree(d_er); hipFree(d_mr);
-  hipStreamDestroy(st);
+  (void)hipFree(d_r); (void)hipFree(d_n); (void)hipFree(d_rv); (void)hipFree(d_res); (void)hipFree(d_np);
+  (void)hipFree(d_sc); (void)hipFree(d_ev); (void)hipFree(d_er); (void)hipFree(d_mr);
+  (void)hipStreamDestroy(st);
   return rc;
 #undef DEV_CHK
 #undef DEV_TRY
@@ -434,6 +437,25 @@ int rays_hip_trace(const rays_params_t* p, int nray, const double* rvec0, const 
   return 0;
 }
 
+int rays_hip_pack_device(int nray, int nv, int nstep_max, const int32_t* d_npoints,
+                         const int64_t* d_offsets, const double* d_ray_vec, const double* d_residual,
+                         double* d_packed_vec, double* d_packed_res, void* hip_stream) {
+  hipError_t e = rays::launch_pack(true, nray, nv, nstep_max, d_npoints, (const long long*)d_offsets,
+                                   const_cast<double*>(d_ray_vec), const_cast<double*>(d_residual),
+                                   d_packed_vec, d_packed_res, (hipStream_t)hip_stream);
+  return e == hipSuccess ? 0 : hip_fail(e, "rays_hip_pack_device");
+}
+
+int rays_hip_unpack_device(int nray, int nv, int nstep_max, const int32_t* d_npoints,
+                           const int64_t* d_offsets, const double* d_packed_vec,
+                           const double* d_packed_res, double* d_ray_vec, double* d_residual,
+                           void* hip_stream) {
+  hipError_t e = rays::launch_pack(false, nray, nv, nstep_max, d_npoints, (const long long*)d_offsets,
+                                   d_ray_vec, d_residual, const_cast<double*>(d_packed_vec),
+                                   const_cast<double*>(d_packed_res), (hipStream_t)hip_stream);
+  return e == hipSuccess ? 0 : hip_fail(e, "rays_hip_unpack_device");
+}
+
 // Diagnostic entry (tests): evaluate the RHS pieces at n states on the current device.
 // v[n][nv] host; outputs host: cold7[n][7], num7[n][7], dvds[n][nv], resid[n], codes[n][4]
 // (codes: equilibrium err, eqn_ray stop code, check_save flag, check_save stop_ode).
@@ -461,7 +483,7 @@ int rays_hip_probe(const rays_params_t* p, int n, const double* v, double* cold7
   HIP_TRY(hipMemcpy(dvds, d_f, sizeof(double) * nv * n, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(resid, d_r, sizeof(double) * n, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(codes, d_k, sizeof(int) * 4 * n, hipMemcpyDeviceToHost));
-  hipFree(d_v); hipFree(d_c); hipFree(d_n); hipFree(d_f); hipFree(d_r); hipFree(d_k);
+  (void)hipFree(d_v); (void)hipFree(d_c); (void)hipFree(d_n); (void)hipFree(d_f); (void)hipFree(d_r); (void)hipFree(d_k);
   return 0;
 }
 

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "librays_hip.so")
 EXPORTED_SYMBOLS = (
     "rays_hip_init", "rays_hip_finalize", "rays_hip_device_count", "rays_hip_last_error",
     "rays_hip_stop_flag_text", "rays_hip_check_params", "rays_hip_trace", "rays_hip_trace_device",
-    "rays_hip_kernel_name", "rays_hip_probe",
+    "rays_hip_kernel_name", "rays_hip_probe", "rays_hip_pack_device", "rays_hip_unpack_device",
 )
 
 _lib = None
@@ -57,6 +57,10 @@ def load():
     lib.rays_hip_trace.argtypes = [pp, C.c_int, dp, dp, dp, dp, ip, ip, dp, dp, dp, dp]
     lib.rays_hip_trace_device.restype = C.c_int
     lib.rays_hip_trace_device.argtypes = [pp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
+    lib.rays_hip_pack_device.restype = C.c_int
+    lib.rays_hip_pack_device.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    lib.rays_hip_unpack_device.restype = C.c_int
+    lib.rays_hip_unpack_device.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     lib.rays_hip_probe.restype = C.c_int
     lib.rays_hip_probe.argtypes = [pp, C.c_int, dp, dp, dp, dp, dp, ip]
     _lib = lib
@@ -126,6 +130,20 @@ def trace_device(p: RaysParams, nray: int, d_rvec0: int, d_rindex_vec0: int, d_r
         d_end_ray_vec or None, d_end_residuals or None, d_max_residuals or None, stream or None,
         0 if zero_fill else 1)
     _check(rc, "rays_hip_trace_device")
+
+
+def pack_device(nray, nv, nstep_max, d_npoints, d_offsets, d_ray_vec, d_residual, d_packed_vec,
+                d_packed_res, stream=0):
+    _check(load().rays_hip_pack_device(int(nray), int(nv), int(nstep_max), d_npoints, d_offsets,
+                                       d_ray_vec, d_residual, d_packed_vec, d_packed_res,
+                                       stream or None), "rays_hip_pack_device")
+
+
+def unpack_device(nray, nv, nstep_max, d_npoints, d_offsets, d_packed_vec, d_packed_res, d_ray_vec,
+                  d_residual, stream=0):
+    _check(load().rays_hip_unpack_device(int(nray), int(nv), int(nstep_max), d_npoints, d_offsets,
+                                         d_packed_vec, d_packed_res, d_ray_vec, d_residual,
+                                         stream or None), "rays_hip_unpack_device")
 
 
 def probe(p: RaysParams, v) -> dict:
