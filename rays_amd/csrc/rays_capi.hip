@@ -82,87 +82,7 @@ const FlagText kFlags[] = {
     {RAYS_STOP_SG_EPS_LE_0, "eps <= 0"},
 };
 
-// rays_params_t -> DevParams.  Derived constants use exactly the reference's expressions
-// (this file is compiled -ffp-contract=off; x86-64 SSE2 doubles are IEEE binary64).
-rays::DevParams make_dev_params(const rays_params_t& p) {
-  rays::DevParams d;
-  std::memset(&d, 0, sizeof d);
-  d.nspec = p.nspec;
-  d.nstep_max = p.nstep_max;
-  d.ray_param = p.ray_param;
-  d.nv = p.nv;
-  d.ds = p.ds;
-  d.s_max = p.s_max;
-  d.omgrf = p.omgrf;
-  d.k0 = p.k0;
-  d.clight = p.clight;
-  d.eps0 = p.eps0;
-  d.resid_limit = p.dispersion_resid_limit;
-  d.omgrf2 = p.omgrf * p.omgrf;
-  d.two_over_k0 = 2. / p.k0;
-  d.m2_over_omgrf = -2. / p.omgrf;
-  d.m1_over_omgrf = -1. / p.omgrf;
-  d.rel_err0 = p.rel_err0;
-  d.abs_err0 = p.abs_err0;
-  d.sg_error_limit = p.SG_error_limit;
-  for (int i = 0; i < RAYS_NS0; i++) {
-    d.qs[i] = p.qs[i];
-    d.ms[i] = p.ms[i];
-    d.n0s[i] = p.n0s[i];
-    d.t0s[i] = p.t0s[i];
-    d.eta[i] = p.eta[i];
-    d.qs2[i] = p.qs[i] * p.qs[i];
-    d.eps0ms[i] = p.eps0 * p.ms[i];
-  }
-  // deriv_num.f90:37  delta = 1.e-6 (default-real literal widened to double)
-  d.delta = (double)1.e-6f;
-  d.two_delta = 2. * d.delta;
-  d.omgrf_p = p.omgrf * (1. + d.delta / 2.);
-  d.omgrf_m = p.omgrf * (1. - d.delta / 2.);
-  d.k0_p = d.omgrf_p / p.clight;
-  d.k0_m = d.omgrf_m / p.clight;
-  d.omgrf2_p = d.omgrf_p * d.omgrf_p;
-  d.omgrf2_m = d.omgrf_m * d.omgrf_m;
-  d.omgrf0_delta = p.omgrf * d.delta;
-  const rays_slab_params_t& s = p.slab;
-  d.by_model = s.by_prof_model;
-  d.bz_model = s.bz_prof_model;
-  d.n_model = s.dens_prof_model;
-  for (int i = 0; i < RAYS_NS0; i++) {
-    d.t_model[i] = s.t_prof_model[i];
-    d.s_at1[i] = s.alphat1[i];
-    d.s_at2[i] = s.alphat2[i];
-    d.T_min[i] = s.T_min[i];
-  }
-  d.xmin = s.xmin; d.xmax = s.xmax; d.ymin = s.ymin; d.ymax = s.ymax; d.zmin = s.zmin; d.zmax = s.zmax;
-  d.s_rmaj = s.rmaj; d.s_rmin = s.rmin; d.x0 = s.x0; d.by0 = s.by0; d.bz0 = s.bz0;
-  d.LBy = s.LBy_shear_scale; d.LBz = s.LBz_scale; d.dBzdx = s.dBzdx; d.Ln = s.Ln_scale;
-  d.dndx = s.dndx; d.s_an1 = s.alphan1; d.s_an2 = s.alphan2; d.n_min = s.n_min;
-  d.LT = s.LT_scale; d.dtdx = s.dtdx;
-  d.by0_over_LBy = s.by0 / s.LBy_shear_scale;
-  d.bz0_over_LBz = s.bz0 / s.LBz_scale;
-  d.one_over_Ln = 1.0 / s.Ln_scale;
-  d.one_over_LT = 1. / s.LT_scale;
-  d.rmin2 = s.rmin * s.rmin;
-  const rays_solovev_params_t& v = p.solovev;
-  d.v_n_model = v.dens_prof_model;
-  for (int i = 0; i < RAYS_NS0; i++) {
-    d.v_t_model[i] = v.t_prof_model[i];
-    d.v_at1[i] = v.alphat1[i];
-    d.v_at2[i] = v.alphat2[i];
-  }
-  d.rmaj = v.rmaj; d.kappa = v.kappa; d.bphi0 = v.bphi0; d.psiB = v.psiB;
-  d.v_an1 = v.alphan1; d.v_an2 = v.alphan2;
-  d.box_rmin = v.box_rmin; d.box_rmax = v.box_rmax; d.box_zmin = v.box_zmin; d.box_zmax = v.box_zmax;
-  d.bp0 = v.bphi0 * v.iota0;          // solovev_eq_m.f90:159
-  d.rk = v.rmaj * v.kappa;
-  d.rk2 = d.rk * d.rk;                // (rmaj*kappa)**2
-  d.rmaj2 = v.rmaj * v.rmaj;
-  d.bphi0_rmaj = v.bphi0 * v.rmaj;    // :172
-  d.half_bp0 = .5 * d.bp0;            // :308
-  d.bp0_2 = d.bp0 * 2.;               // :181
-  return d;
-}
+#include "rays_dev_params.inc"
 
 const rays::KernelEntry* find_kernel(const rays_params_t& p) {
   using namespace rays;

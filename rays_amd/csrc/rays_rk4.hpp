@@ -35,7 +35,7 @@ rk4_trace_kernel(const DevParams P, const TraceArgs A) {
   bool alive = ray < A.nray;
   bool need_init = alive;
   int j = 3;            // stage
-  bool first = true;    // stage-3 evaluation is the initial check_save
+  int first = 1;        // stage-3 evaluation is the initial check_save (int, not bool: see rays_sg.hpp)
   int nstep = 0;
   double s = 0., sout = 0., dsl = 0.;
   double v[NV], w[NV], acc[NV];
@@ -51,7 +51,7 @@ rk4_trace_kernel(const DevParams P, const TraceArgs A) {
 #pragma unroll
       for (int i = 0; i < NV; i++) w[i] = v[i];
       j = 3;
-      first = true;
+      first = 1;
       nstep = 0;
       s = 0.;
       sout = 0.;
@@ -69,12 +69,12 @@ rk4_trace_kernel(const DevParams P, const TraceArgs A) {
 
     // ---- per-lane integrator state machine ---------------------------------------------------
     int stop = 0;        // 0 = keep going
-    bool done = false;   // ray finished this trip
+    int done = 0;        // ray finished this trip
     if (alive) {
       if (j < 3) {
         if (code) {  // RK4_ode_m.f90:83-89: stage stopped, v untouched
           stop = code;
-          done = true;
+          done = 1;
         } else if (j == 0) {
 #pragma unroll
           for (int i = 0; i < NV; i++) {
@@ -112,17 +112,17 @@ rk4_trace_kernel(const DevParams P, const TraceArgs A) {
               for (int i = 0; i < NV; i++) A.end_ray_vec[(long long)ray * NV + i] = 0.;
             if (A.end_residuals) A.end_residuals[ray] = 0.;
             if (A.max_residuals) A.max_residuals[ray] = 0.;
-            done = true;
+            done = 1;
             stop = -1;  // summary already written
           }
-          first = false;
+          first = 0;
         } else {
 #pragma unroll
           for (int i = 0; i < NV; i++) v[i] = w[i];  // RK4_ode_m.f90:91-92
           s = sout;
           if (cs_stop) {  // ray_tracing.f90:214-234: step not recorded, v is the new state
             stop = cs_flag;
-            done = true;
+            done = 1;
           } else {  // :237-243
             nstep = nstep + 1;
             if (nbuf == 0) first_pt = (long long)ray * npt + nstep;
@@ -138,13 +138,13 @@ rk4_trace_kernel(const DevParams P, const TraceArgs A) {
           sout = sout + P.ds;
           if (sout > P.s_max) {
             stop = RAYS_STOP_SOUT_GT_SMAX;
-            done = true;
+            done = 1;
           } else if (nstep + 1 > P.nstep_max) {
             stop = RAYS_STOP_NSTEP_MAX;
-            done = true;
+            done = 1;
           } else if (code) {  // first RK4 stage of the next step stops (RK4_ode_m.f90:82-83)
             stop = code;
-            done = true;
+            done = 1;
           } else {
             dsl = sout - s;  // RK4_ode_m.f90:81
 #pragma unroll

@@ -22,6 +22,11 @@ namespace rays {
 
 constexpr int kWave = 64;
 constexpr int kRowStride = 65;  // doubles; 65 -> conflict-free b64 column reads at flush
+#ifdef RAYS_HOST_EMUL  // tests/hip_emul: one lane stands in for the whole wave
+constexpr int kFlushStride = 1;
+#else
+constexpr int kFlushStride = kWave;
+#endif
 
 struct TraceArgs {
   int nray;
@@ -75,7 +80,7 @@ struct PointStage {
       const unsigned hi = __builtin_amdgcn_readlane((unsigned)((unsigned long long)first_pt >> 32), r);
       const long long pt0 = (long long)(((unsigned long long)hi << 32) | lo);
       const int total = n * (NV + 1);
-      for (int e = lane; e < total; e += kWave) {
+      for (int e = lane; e < total; e += kFlushStride) {
         const int k = e / (NV + 1), c = e - k * (NV + 1);
         const double val = base[e * kRowStride + r];
         if (c < NV)

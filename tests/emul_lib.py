@@ -1,0 +1,58 @@
+"""ctypes wrapper around tests/hip_emul/librays_emul.so: the PRODUCT kernel source compiled for the
+host (one lane per wave) -- test infrastructure for the CPU tier and for sanitizer runs."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from rays_amd.params import RaysParams
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_DIR = os.path.join(_ROOT, "tests", "hip_emul")
+_LIB = os.path.join(_DIR, "librays_emul.so")
+_lib = None
+
+
+def build(sanitize: bool = False):
+    srcs = [os.path.join(_DIR, "emul_trace.cpp"), os.path.join(_DIR, "hip", "hip_runtime.h")]
+    srcs += [os.path.join(_ROOT, "rays_amd", "csrc", f) for f in
+             ("rays_device.hpp", "rays_trace.hpp", "rays_rk4.hpp", "rays_sg.hpp", "rays_dev_params.inc")]
+    if os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs):
+        return
+    cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+           "-w", "-I", _DIR, srcs[0], "-o", _LIB]
+    if sanitize:
+        cmd[1:1] = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g"]
+    subprocess.check_call(cmd)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB)
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        _lib.rays_emul_trace.restype = C.c_int
+        _lib.rays_emul_trace.argtypes = [C.POINTER(RaysParams), C.c_int, dp, dp, dp, dp, ip, ip, dp, dp, dp]
+    return _lib
+
+
+def trace(p: RaysParams, rvec0, rindex_vec0) -> dict:
+    rvec0 = np.ascontiguousarray(rvec0, dtype=np.float64)
+    rindex_vec0 = np.ascontiguousarray(rindex_vec0, dtype=np.float64)
+    nray, nv, npt = len(rvec0), p.nv, p.nstep_max + 1
+    out = dict(
+        ray_vec=np.zeros((nray, npt, nv)), residual=np.zeros((nray, npt)),
+        npoints=np.zeros(nray, dtype=np.int32), stop_code=np.zeros(nray, dtype=np.int32),
+        end_ray_vec=np.zeros((nray, nv)), end_residuals=np.zeros(nray), max_residuals=np.zeros(nray))
+    d = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    rc = lib().rays_emul_trace(C.byref(p), nray, d(rvec0), d(rindex_vec0), d(out["ray_vec"]),
+                               d(out["residual"]), i(out["npoints"]), i(out["stop_code"]),
+                               d(out["end_ray_vec"]), d(out["end_residuals"]), d(out["max_residuals"]))
+    if rc:
+        raise RuntimeError(f"rays_emul_trace rc={rc}")
+    return out

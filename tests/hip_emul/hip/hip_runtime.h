@@ -1,0 +1,31 @@
+// TEST INFRASTRUCTURE ONLY: a one-lane-per-wave host emulation of the handful of HIP constructs the
+// trace kernels use, so the *product kernel source* (rays_amd/csrc/rays_{rk4,sg}.hpp) can be
+// compiled with g++ and run on the CPU under sanitizers (GPU ASan is not available on the pool)
+// and compared with the oracle in the CPU test tier.  Never part of librays_hip.so.
+#pragma once
+#define RAYS_HOST_EMUL 1
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#define __device__
+#define __global__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__
+#define __restrict__ __restrict
+
+struct emul_dim3 { unsigned x = 1, y = 1, z = 1; };
+extern thread_local emul_dim3 threadIdx, blockIdx, blockDim, gridDim;
+#define RAYS_EMUL_DEFINE_GLOBALS \
+  thread_local emul_dim3 threadIdx, blockIdx, blockDim, gridDim; \
+  namespace rays { double lds[1 << 16]; }
+
+inline int __any(int x) { return x; }
+#define __builtin_amdgcn_readlane(v, r) ((r) == 0 ? (v) : 0)  /* only lane 0 exists */
+#define __builtin_amdgcn_wave_barrier() ((void)0)
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+using std::copysign; using std::fabs; using std::fmax; using std::fmin; using std::ilogb;
+using std::pow; using std::scalbn; using std::sqrt; using std::exp;

@@ -10,6 +10,7 @@ from tests.common import GOLDEN_CASES, assert_matches_golden, load_golden
 pytestmark = pytest.mark.gpu
 
 RK4_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_num"]
+SG_CASES = ["gold_solovev64_sg_cold", "gold_solovev64_sg_num"]
 
 
 @pytest.mark.parametrize("name", RK4_CASES)
@@ -18,6 +19,41 @@ def test_rk4_matches_reference_golden(name):
     out = hip.trace_host(p, g["rvec0"], g["rindex_vec0"], ngpu=1)
     worst = assert_matches_golden(out, g, p)
     print(f"{name}: worst rel err vs reference {worst:.3e}")
+
+
+@pytest.mark.parametrize("name", SG_CASES)
+def test_sg_matches_reference_golden(name):
+    """Shampine-Gordon adaptive stepper (+ numerical dD): exact npoints / stop flags incl.
+    'equations stiff', 'ODE total error' and box exits; trajectories within 1e-10."""
+    g, nml, p = load_golden(name)
+    out = hip.trace_host(p, g["rvec0"], g["rindex_vec0"], ngpu=1)
+    worst = assert_matches_golden(out, g, p)
+    print(f"{name}: worst rel err vs reference {worst:.3e}")
+
+
+@pytest.mark.parametrize("name", SG_CASES)
+def test_sg_full_fan_matches_oracle(name):
+    g, nml, p = load_golden(name)
+    out = hip.trace_host(p, g["rvec0_full"], g["rindex_vec0_full"], ngpu=1)
+    np.testing.assert_array_equal(out["npoints"], g["npoints_full"])
+    ora = oracle_lib.trace(p, g["rvec0_full"], g["rindex_vec0_full"])
+    np.testing.assert_array_equal(out["stop_code"], ora["stop_code"])
+    rel = 0.0
+    per_ray = np.zeros(len(ora["npoints"]))
+    for sl in (slice(0, 3), slice(3, 6)):
+        num = np.linalg.norm(out["ray_vec"][..., sl] - ora["ray_vec"][..., sl], axis=-1)
+        den = np.maximum(np.linalg.norm(ora["ray_vec"][..., sl], axis=-1), 1e-300)
+        per_ray = np.maximum(per_ray, (num / den).max(axis=1))
+    nbit = int((np.abs(out["ray_vec"] - ora["ray_vec"]).max(axis=(1, 2)) == 0).sum())
+    print(f"{name}: {nbit}/{len(per_ray)} rays bitwise, worst accumulated rel err {per_ray.max():.3e}")
+    if p.ray_deriv == 0:
+        assert per_ray.max() <= 1e-10
+    else:
+        # SG + finite-difference dD: the step-size update calls libm pow (ode_RAYS.f90:1222); a
+        # 1-ulp difference between ocml and glibc pow moves h by 1 ulp, and the finite-difference
+        # derivatives (noise floor ~1e-10, SURVEY App. A) amplify that along a few rays.  Counts and
+        # stop flags stay exact; >= 90 % of rays stay within 1e-10, all within 1e-6 (DESIGN.md).
+        assert (per_ray <= 1e-10).mean() >= 0.9 and per_ray.max() <= 1e-6
 
 
 @pytest.mark.parametrize("name", ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4"])
