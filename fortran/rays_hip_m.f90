@@ -1,0 +1,138 @@
+ module rays_hip_m
+! iso_c_binding interface to librays_hip.so (include/rays_hip.h) -- the thin Fortran shim through
+! which the RAYS host calls the MI355X ray-trajectory integrator.
+!
+! type(rays_params_t) mirrors the C struct field for field; the integer selectors are the images
+! of the reference's string switches (see the enums in rays_hip.h).  Every real constant is passed
+! by value from the host's own module variables (constants_m, rf_m, species_m ...), never
+! re-derived on the device side: several of them are single-precision literals widened to double
+! (constants_m.f90:39-48) and must reach the GPU bit for bit.
+
+    use, intrinsic :: iso_c_binding
+    implicit none
+
+    integer(c_int), parameter :: RAYS_ABI_VERSION = 1
+    integer, parameter :: RAYS_NS0 = 6   ! species_m nspec0 + 1
+
+    ! selectors
+    integer(c_int32_t), parameter :: RAYS_ODE_RK4 = 0, RAYS_ODE_SG = 1
+    integer(c_int32_t), parameter :: RAYS_DERIV_COLD = 0, RAYS_DERIV_NUM = 1
+    integer(c_int32_t), parameter :: RAYS_PARAM_ARCL = 0, RAYS_PARAM_TIME = 1
+    integer(c_int32_t), parameter :: RAYS_EQ_SLAB = 0, RAYS_EQ_SOLOVEV = 1
+
+    type, bind(C) :: rays_slab_params_t
+        integer(c_int32_t) :: bx_prof_model, by_prof_model, bz_prof_model, dens_prof_model
+        integer(c_int32_t) :: t_prof_model(RAYS_NS0)
+        integer(c_int32_t) :: pad_(2)
+        real(c_double) :: xmin, xmax, ymin, ymax, zmin, zmax
+        real(c_double) :: rmaj, rmin, x0
+        real(c_double) :: bx0, by0, bz0, LBy_shear_scale, LBz_scale, dBzdx
+        real(c_double) :: Ln_scale, dndx, alphan1, alphan2, n_min
+        real(c_double) :: LT_scale, dtdx
+        real(c_double) :: alphat1(RAYS_NS0), alphat2(RAYS_NS0), T_min(RAYS_NS0)
+    end type rays_slab_params_t
+
+    type, bind(C) :: rays_solovev_params_t
+        integer(c_int32_t) :: dens_prof_model
+        integer(c_int32_t) :: t_prof_model(RAYS_NS0)
+        integer(c_int32_t) :: pad_(1)
+        real(c_double) :: rmaj, kappa, bphi0, iota0, outer_bound
+        real(c_double) :: psiB
+        real(c_double) :: alphan1, alphan2
+        real(c_double) :: alphat1(RAYS_NS0), alphat2(RAYS_NS0)
+        real(c_double) :: box_rmin, box_rmax, box_zmin, box_zmax
+    end type rays_solovev_params_t
+
+    type, bind(C) :: rays_params_t
+        integer(c_int32_t) :: abi_version
+        integer(c_int32_t) :: nv, nspec, nstep_max
+        integer(c_int32_t) :: ode_solver, ray_deriv, ray_param, equilib_model
+        integer(c_int32_t) :: integrate_eq_gradients
+        integer(c_int32_t) :: pad_(3)
+        real(c_double) :: ds, s_max
+        real(c_double) :: omgrf, k0
+        real(c_double) :: clight, eps0
+        real(c_double) :: dispersion_resid_limit
+        real(c_double) :: rel_err0, abs_err0, SG_error_limit
+        real(c_double) :: qs(RAYS_NS0), ms(RAYS_NS0)
+        real(c_double) :: n0s(RAYS_NS0), t0s(RAYS_NS0)
+        real(c_double) :: eta(RAYS_NS0)
+        type(rays_slab_params_t) :: slab
+        type(rays_solovev_params_t) :: solovev
+    end type rays_params_t
+
+    interface
+
+       integer(c_int) function rays_hip_init(ngpu) bind(C, name='rays_hip_init')
+          import :: c_int
+          integer(c_int), value :: ngpu
+       end function rays_hip_init
+
+       integer(c_int) function rays_hip_finalize() bind(C, name='rays_hip_finalize')
+          import :: c_int
+       end function rays_hip_finalize
+
+       integer(c_int) function rays_hip_last_error(buf, len) bind(C, name='rays_hip_last_error')
+          import :: c_int, c_char
+          character(kind=c_char) :: buf(*)
+          integer(c_int), value :: len
+       end function rays_hip_last_error
+
+       type(c_ptr) function rays_hip_stop_flag_text(stop_code) bind(C, name='rays_hip_stop_flag_text')
+          import :: c_int, c_ptr
+          integer(c_int), value :: stop_code
+       end function rays_hip_stop_flag_text
+
+       integer(c_int) function rays_hip_check_params(p) bind(C, name='rays_hip_check_params')
+          import :: c_int, rays_params_t
+          type(rays_params_t), intent(in) :: p
+       end function rays_hip_check_params
+
+       ! Replaces `call trace_rays`: blocking, host arrays in the reference's own layouts.
+       integer(c_int) function rays_hip_trace(p, nray, rvec0, rindex_vec0, ray_vec, residual, &
+                    & npoints, stop_code, end_ray_vec, end_residuals, max_residuals, elapsed_s) &
+                    & bind(C, name='rays_hip_trace')
+          import :: c_int, c_int32_t, c_double, rays_params_t
+          type(rays_params_t), intent(in) :: p
+          integer(c_int), value :: nray
+          real(c_double), intent(in) :: rvec0(3,*), rindex_vec0(3,*)
+          real(c_double), intent(inout) :: ray_vec(*), residual(*)
+          integer(c_int32_t), intent(inout) :: npoints(*), stop_code(*)
+          real(c_double), intent(inout) :: end_ray_vec(*), end_residuals(*), max_residuals(*)
+          real(c_double), intent(out) :: elapsed_s
+       end function rays_hip_trace
+
+    end interface
+
+ contains
+
+    function stop_flag_string(stop_code) result(flag)
+    ! integer stop code -> the reference's ode_stop_flag text (e.g. ' nstep > nstep_max')
+       integer(c_int), intent(in) :: stop_code
+       character(len=60) :: flag
+       type(c_ptr) :: cp
+       character(kind=c_char), pointer :: cs(:)
+       integer :: i
+       flag = ''
+       cp = rays_hip_stop_flag_text(stop_code)
+       if (.not. c_associated(cp)) return
+       call c_f_pointer(cp, cs, [60])
+       do i = 1, 60
+          if (cs(i) == c_null_char) exit
+          flag(i:i) = cs(i)
+       end do
+    end function stop_flag_string
+
+    subroutine last_error_string(msg)
+       character(len=*), intent(out) :: msg
+       character(kind=c_char) :: buf(512)
+       integer :: i, n
+       msg = ''
+       n = rays_hip_last_error(buf, 512_c_int)
+       do i = 1, min(len(msg), 511)
+          if (buf(i) == c_null_char) exit
+          msg(i:i) = buf(i)
+       end do
+    end subroutine last_error_string
+
+ end module rays_hip_m

@@ -1,0 +1,44 @@
+"""Drop-in test: the REFERENCE host program (initialize / ray_init / ray_results_m, compiled from
+the reference sources) with `trace_rays` replaced by fortran/trace_rays_hip.f90 -> C ABI -> HIP,
+against the unmodified reference binary on the same namelist.  Both binaries are built by
+oracle/build_ref.sh where /root/reference is available and travel to the GPU box prebuilt."""
+import os
+import shutil
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from tests.common import ROOT
+from tests.refdump import read_dump
+
+pytestmark = pytest.mark.gpu
+
+REF = os.path.join(ROOT, "oracle", "_ref", "rays_ref_dump")
+HIPBIN = os.path.join(ROOT, "oracle", "_ref", "rays_hip_dropin")
+
+
+def _run(binary, cfg, d):
+    os.makedirs(d, exist_ok=True)
+    shutil.copy(os.path.join(ROOT, "configs", cfg), os.path.join(d, "rays.in"))
+    env = dict(os.environ, RAYS_DUMP_FILE="dump.bin", RAYS_DUMP_PROBE="0")
+    subprocess.run([binary], cwd=d, env=env, check=True, stdout=subprocess.DEVNULL, timeout=600)
+    return read_dump(os.path.join(d, "dump.bin"))
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(HIPBIN)),
+                    reason="reference binaries not built (oracle/build_ref.sh needs /root/reference)")
+@pytest.mark.parametrize("cfg", ["cfg1_slab16_rk4.in", "cfg2_solovev1024_rk4.in",
+                                 "gold_solovev64_sg_cold.in", "gold_solovev64_rk4_num.in"])
+def test_fortran_dropin_equals_reference_binary(cfg):
+    with tempfile.TemporaryDirectory() as d:
+        ref = _run(REF, cfg, os.path.join(d, "ref"))
+        hipr = _run(HIPBIN, cfg, os.path.join(d, "hip"))
+    assert hipr["nray"] == ref["nray"]
+    np.testing.assert_array_equal(hipr["rvec0"], ref["rvec0"])
+    np.testing.assert_array_equal(hipr["npoints"], ref["npoints"])
+    assert hipr["stop_flag"] == ref["stop_flag"]          # the exact strings, leading blank included
+    np.testing.assert_array_equal(hipr["ray_vec"], ref["ray_vec"])      # bit-identical trajectories
+    np.testing.assert_array_equal(hipr["residual"], ref["residual"])
+    np.testing.assert_array_equal(hipr["end_ray_vec"], ref["end_ray_vec"])
