@@ -148,8 +148,9 @@ def main():
 
     nml, p, r0, n0 = build_fan(args.config, world)
     nray_total = len(r0)
-    per = (nray_total + world - 1) // world
-    lo, hi = min(nray_total, rank * per), min(nray_total, (rank + 1) * per)
+    from rays_amd.exchange import shard_bounds
+
+    lo, hi = shard_bounds(nray_total, world, rank)
     tr = DeviceTrace(p, r0[lo:hi], n0[lo:hi], device=dev)
     nv, npt = p.nv, p.nstep_max + 1
 
@@ -160,55 +161,16 @@ def main():
     steps_local = int(torch.clamp(npts_local - 1, min=0).sum().item())
     points_local = int(npts_local.sum().item())
 
-    # ---- multi-GPU exchange state: compact (CSR) trajectories, grouped send/recv to rank 0 ----
+    # ---- multi-GPU exchange: packed trajectories, grouped send/recv to rank 0 (rays_amd/exchange.py)
     gather = None
     if world > 1 and not args.no_gather:
-        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(counts, torch.tensor([points_local], dtype=torch.int64, device=dev))
-        counts = [int(c.item()) for c in counts]
-        nrays = [min(nray_total, (r + 1) * per) - min(nray_total, r * per) for r in range(world)]
-        offsets = torch.zeros(hi - lo, dtype=torch.int64, device=dev)
-        packed_vec = torch.empty((max(points_local, 1), nv), dtype=torch.float64, device=dev)
-        packed_res = torch.empty(max(points_local, 1), dtype=torch.float64, device=dev)
-        if rank == 0:
-            g_ray_vec = torch.zeros((nray_total, npt, nv), dtype=torch.float64, device=dev)
-            g_residual = torch.zeros((nray_total, npt), dtype=torch.float64, device=dev)
-            g_npoints = [torch.zeros(n, dtype=torch.int32, device=dev) for n in nrays]
-            g_stop = [torch.zeros(n, dtype=torch.int32, device=dev) for n in nrays]
-            r_vec = [None] + [torch.empty((max(c, 1), nv), dtype=torch.float64, device=dev) for c in counts[1:]]
-            r_res = [None] + [torch.empty(max(c, 1), dtype=torch.float64, device=dev) for c in counts[1:]]
-            r_off = [torch.zeros(n, dtype=torch.int64, device=dev) for n in nrays]
+        from rays_amd.exchange import TrajectoryGather
+
+        tg = TrajectoryGather(nray_total, nv, p.nstep_max, dev)
+        tg.prepare(tr.npoints)
 
         def gather():
-            stream = torch.cuda.current_stream().cuda_stream
-            torch.cumsum(tr.npoints, 0, dtype=torch.int64, out=offsets)
-            offsets.sub_(tr.npoints)  # exclusive prefix
-            hip.pack_device(hi - lo, nv, p.nstep_max, tr.npoints.data_ptr(), offsets.data_ptr(),
-                            tr.ray_vec.data_ptr(), tr.residual.data_ptr(), packed_vec.data_ptr(),
-                            packed_res.data_ptr(), stream)
-            if rank == 0:
-                ops = []
-                for r in range(1, world):
-                    ops += [dist.P2POp(dist.irecv, g_npoints[r], r), dist.P2POp(dist.irecv, g_stop[r], r),
-                            dist.P2POp(dist.irecv, r_vec[r], r), dist.P2POp(dist.irecv, r_res[r], r)]
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
-                # own slab is already padded: copy; peers: unpack into their slab of the global arrays
-                g_ray_vec[0:nrays[0]].copy_(tr.ray_vec)
-                g_residual[0:nrays[0]].copy_(tr.residual)
-                for r in range(1, world):
-                    torch.cumsum(g_npoints[r], 0, dtype=torch.int64, out=r_off[r])
-                    r_off[r].sub_(g_npoints[r])
-                    b = min(nray_total, r * per)
-                    hip.unpack_device(nrays[r], nv, p.nstep_max, g_npoints[r].data_ptr(), r_off[r].data_ptr(),
-                                      r_vec[r].data_ptr(), r_res[r].data_ptr(),
-                                      g_ray_vec[b:b + nrays[r]].data_ptr(), g_residual[b:b + nrays[r]].data_ptr(),
-                                      stream)
-            else:
-                ops = [dist.P2POp(dist.isend, tr.npoints, 0), dist.P2POp(dist.isend, tr.stop_code, 0),
-                       dist.P2POp(dist.isend, packed_vec, 0), dist.P2POp(dist.isend, packed_res, 0)]
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
+            tg.gather(tr.ray_vec, tr.residual, tr.npoints, tr.stop_code)
 
     def step(ev=None):
         if ev is not None:

@@ -137,6 +137,9 @@ typedef struct rays_params {
 int rays_hip_init(int ngpu);
 int rays_hip_finalize(void);
 int rays_hip_device_count(void);
+/* sizeof(rays_params_t) as compiled into the library: lets a foreign-language binding (ctypes,
+ * iso_c_binding) verify its mirror of the struct. */
+int rays_hip_sizeof_params(void);
 /* Copies the last error message (NUL-terminated, truncated to len) and returns its length. */
 int rays_hip_last_error(char* buf, int len);
 /* Reference ode_stop_flag text for a stop code (e.g. " nstep > nstep_max"); "" if unknown. */

@@ -135,6 +135,8 @@ const char* rays_hip_stop_flag_text(int stop_code) {
   return "";
 }
 
+int rays_hip_sizeof_params(void) { return (int)sizeof(rays_params_t); }
+
 int rays_hip_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

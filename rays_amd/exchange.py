@@ -1,0 +1,141 @@
+"""Multi-GPU side of the hot path: ray sharding and the final trajectory gather.
+
+Rays are independent, so the only exchange is the gather of each rank's trajectories to rank 0
+(the reference writes straight into shared arrays from its OpenMP threads, ray_tracing.f90:62-64).
+
+  * partition: contiguous blocks, rank r owns rays [r*per, (r+1)*per) -- the reference's
+    `schedule(static)`; a block is a contiguous slab of ray_vec(nv, nstep_max+1, nray).
+  * payload: the padded slab is ~80 % zeros (a ray uses npoints of nstep_max+1 slots), so each
+    rank packs its slab to [sum(npoints)][nv] (+ residual) first; rank 0 receives every peer's
+    packed block with grouped send/recv (one RCCL group: each peer uses its own xGMI link to the
+    root, so the transfers are link-parallel, not ring-bound) and unpacks it into the peer's slab
+    of the padded global arrays.
+  * no other collective exists on this path.
+
+pack / unpack are injected: on GPUs they are the HIP kernels of librays_hip.so
+(rays_hip_pack_device / rays_hip_unpack_device); the world_size-2 gloo test passes CPU stand-ins
+to exercise the protocol without a GPU.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+
+def shard_bounds(nray: int, world: int, rank: int) -> Tuple[int, int]:
+    per = (nray + world - 1) // world
+    return min(nray, rank * per), min(nray, (rank + 1) * per)
+
+
+def hip_pack(nray, nv, nstep_max, npoints, offsets, ray_vec, residual, packed_vec, packed_res, stream):
+    from . import hip
+
+    hip.pack_device(nray, nv, nstep_max, npoints.data_ptr(), offsets.data_ptr(), ray_vec.data_ptr(),
+                    residual.data_ptr(), packed_vec.data_ptr(), packed_res.data_ptr(), stream)
+
+
+def hip_unpack(nray, nv, nstep_max, npoints, offsets, packed_vec, packed_res, ray_vec, residual, stream):
+    from . import hip
+
+    hip.unpack_device(nray, nv, nstep_max, npoints.data_ptr(), offsets.data_ptr(),
+                      packed_vec.data_ptr(), packed_res.data_ptr(), ray_vec.data_ptr(),
+                      residual.data_ptr(), stream)
+
+
+class TrajectoryGather:
+    """Gathers (ray_vec, residual, npoints, stop_code) of all ranks into rank 0's global arrays."""
+
+    def __init__(self, nray_total: int, nv: int, nstep_max: int, device, pack: Callable = hip_pack,
+                 unpack: Callable = hip_unpack, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.group = group
+        self.nray_total, self.nv, self.nstep_max = nray_total, nv, nstep_max
+        self.device = device
+        self.pack, self.unpack = pack, unpack
+        self.bounds = [shard_bounds(nray_total, self.world, r) for r in range(self.world)]
+        self.nrays = [hi - lo for lo, hi in self.bounds]
+        n_local = self.nrays[self.rank]
+        f64, i64, i32 = torch.float64, torch.int64, torch.int32
+        self.offsets = torch.zeros(n_local, dtype=i64, device=device)
+        self._cap = 0
+        self.packed_vec = self.packed_res = None
+        if self.rank == 0:
+            npt = nstep_max + 1
+            self.ray_vec = torch.zeros((nray_total, npt, nv), dtype=f64, device=device)
+            self.residual = torch.zeros((nray_total, npt), dtype=f64, device=device)
+            self.npoints = torch.zeros(nray_total, dtype=i32, device=device)
+            self.stop_code = torch.zeros(nray_total, dtype=i32, device=device)
+            self._r_off = [torch.zeros(n, dtype=i64, device=device) for n in self.nrays]
+            self._r_vec: List[Optional[object]] = [None] * self.world
+            self._r_res: List[Optional[object]] = [None] * self.world
+        self._counts = None
+
+    def _stream(self):
+        t = self.torch
+        return t.cuda.current_stream().cuda_stream if self.device.type == "cuda" else 0
+
+    def prepare(self, npoints_local):
+        """Exchange per-rank point counts and size the buffers (once per fan; not per step)."""
+        t, dist = self.torch, self.dist
+        mine = t.tensor([int(npoints_local.to(t.int64).sum().item())], dtype=t.int64, device=self.device)
+        counts = [t.zeros(1, dtype=t.int64, device=self.device) for _ in range(self.world)]
+        dist.all_gather(counts, mine, group=self.group)
+        self._counts = [int(c.item()) for c in counts]
+        cap = max(self._counts[self.rank], 1)
+        self.packed_vec = t.empty((cap, self.nv), dtype=t.float64, device=self.device)
+        self.packed_res = t.empty(cap, dtype=t.float64, device=self.device)
+        if self.rank == 0:
+            for r in range(1, self.world):
+                c = max(self._counts[r], 1)
+                self._r_vec[r] = t.empty((c, self.nv), dtype=t.float64, device=self.device)
+                self._r_res[r] = t.empty(c, dtype=t.float64, device=self.device)
+
+    def gather(self, ray_vec, residual, npoints, stop_code):
+        t, dist = self.torch, self.dist
+        if self._counts is None:
+            self.prepare(npoints)
+        stream = self._stream()
+        n_local = self.nrays[self.rank]
+        t.cumsum(npoints, 0, dtype=t.int64, out=self.offsets)
+        self.offsets.sub_(npoints)  # exclusive prefix sum
+        self.pack(n_local, self.nv, self.nstep_max, npoints, self.offsets, ray_vec, residual,
+                  self.packed_vec, self.packed_res, stream)
+        if self.rank == 0:
+            lo, hi = self.bounds[0]
+            ops = []
+            for r in range(1, self.world):
+                b0, b1 = self.bounds[r]
+                if b1 == b0:
+                    continue
+                ops += [dist.P2POp(dist.irecv, self.npoints[b0:b1], r, self.group),
+                        dist.P2POp(dist.irecv, self.stop_code[b0:b1], r, self.group),
+                        dist.P2POp(dist.irecv, self._r_vec[r], r, self.group),
+                        dist.P2POp(dist.irecv, self._r_res[r], r, self.group)]
+            works = dist.batch_isend_irecv(ops) if ops else []
+            # own slab is already in the padded layout
+            self.ray_vec[lo:hi].copy_(ray_vec)
+            self.residual[lo:hi].copy_(residual)
+            self.npoints[lo:hi].copy_(npoints)
+            self.stop_code[lo:hi].copy_(stop_code)
+            for w in works:
+                w.wait()
+            for r in range(1, self.world):
+                b0, b1 = self.bounds[r]
+                if b1 == b0:
+                    continue
+                npts = self.npoints[b0:b1]
+                t.cumsum(npts, 0, dtype=t.int64, out=self._r_off[r])
+                self._r_off[r].sub_(npts)
+                self.unpack(b1 - b0, self.nv, self.nstep_max, npts, self._r_off[r], self._r_vec[r],
+                            self._r_res[r], self.ray_vec[b0:b1], self.residual[b0:b1], stream)
+        elif n_local > 0:
+            ops = [dist.P2POp(dist.isend, npoints, 0, self.group),
+                   dist.P2POp(dist.isend, stop_code, 0, self.group),
+                   dist.P2POp(dist.isend, self.packed_vec, 0, self.group),
+                   dist.P2POp(dist.isend, self.packed_res, 0, self.group)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()

@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "librays_hip.so")
 
 # every symbol include/rays_hip.h declares
 EXPORTED_SYMBOLS = (
-    "rays_hip_init", "rays_hip_finalize", "rays_hip_device_count", "rays_hip_last_error",
+    "rays_hip_init", "rays_hip_finalize", "rays_hip_device_count", "rays_hip_sizeof_params",
+    "rays_hip_last_error",
     "rays_hip_stop_flag_text", "rays_hip_check_params", "rays_hip_trace", "rays_hip_trace_device",
     "rays_hip_kernel_name", "rays_hip_probe", "rays_hip_pack_device", "rays_hip_unpack_device",
 )
@@ -45,6 +46,9 @@ def load():
     lib.rays_hip_init.argtypes = [C.c_int]
     lib.rays_hip_finalize.restype = C.c_int
     lib.rays_hip_device_count.restype = C.c_int
+    lib.rays_hip_sizeof_params.restype = C.c_int
+    if lib.rays_hip_sizeof_params() != C.sizeof(RaysParams):
+        raise RaysHipError("rays_params_t layout mismatch between librays_hip.so and rays_amd.params")
     lib.rays_hip_last_error.restype = C.c_int
     lib.rays_hip_last_error.argtypes = [C.c_char_p, C.c_int]
     lib.rays_hip_stop_flag_text.restype = C.c_char_p

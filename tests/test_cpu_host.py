@@ -1,0 +1,110 @@
+"""CPU tier: host logic (namelist, module-state image, ray launchers) and the C-ABI library."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from rays_amd import hip
+from rays_amd.namelist import parse_namelist
+from rays_amd.params import STOP_FLAG_TEXT, ConfigError, RaysParams, params_from_namelist
+from rays_amd.ray_init import initialize_ray_init
+from tests.common import GOLDEN_CASES, ROOT, load_golden
+
+
+def test_namelist_parser():
+    nml = parse_namelist("""
+ &a_list  x=1, y = 2.5e3 name='it''s' ! comment
+   flag=.true. arr(0)= 1. arr(2) = 3.d0 rep=2*'zero' dup = 1 dup = 2
+ /
+ &b_list z = -1 /
+""")
+    a = nml["a_list"]
+    assert a["x"] == 1 and a["y"] == 2500.0 and a["name"] == "it's" and a["flag"] is True
+    assert a["arr"] == {0: 1.0, 2: 3.0} and a["rep"] == ["zero", "zero"] and a["dup"] == 2
+    assert nml["b_list"]["z"] == -1
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_module_state_equals_reference(name):
+    """constants_m / rf_m / species_m / solovev psiB as the reference computed them (bitwise)."""
+    g, nml, p = load_golden(name)
+    omgrf, k0, clight, eps0 = g["consts"]
+    assert (p.omgrf, p.k0, p.clight, p.eps0) == (omgrf, k0, clight, eps0)
+    for key in ("qs", "ms", "n0s", "t0s"):
+        np.testing.assert_array_equal(np.array(getattr(p, key)[:]), g[key])
+    if p.equilib_model == 1:
+        assert p.solovev.psiB == float(g["psiB"])
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_ray_init_equals_reference(name):
+    """simple_slab / solovev n_theta x n_phi launchers: same rays, same order, same bits."""
+    g, nml, p = load_golden(name)
+    r0, n0, _ = initialize_ray_init(p, nml)
+    assert len(r0) == int(g["nray_full"])
+    np.testing.assert_array_equal(r0, g["rvec0_full"])
+    np.testing.assert_array_equal(n0, g["rindex_vec0_full"])
+
+
+def test_evanescent_launches_are_dropped():
+    g, nml, p = load_golden("cfg2_solovev1024_rk4")
+    import copy
+    nml = copy.deepcopy(nml)
+    nml["solovev_ray_init_nphi_ktheta_list"].update(n_rindex_phi=8, rindex_phi0=0.5, delta_rindex_phi=0.2)
+    r0, n0, _ = initialize_ray_init(p, nml)
+    assert 0 < len(r0) < 32 * 8  # large n_phi is evanescent at the launch point
+
+
+def test_config_errors():
+    g, nml, p = load_golden("cfg1_slab16_rk4")
+    import copy
+    bad = copy.deepcopy(nml)
+    bad["ode_list"]["ode_solver_name"] = "EULER"
+    with pytest.raises(ConfigError):
+        params_from_namelist(bad)
+    bad = copy.deepcopy(nml)
+    bad["damping_list"]["damping_model"] = "damp_fund_ECH"
+    with pytest.raises(ConfigError):
+        params_from_namelist(bad)
+
+
+def test_c_abi_library_loads_and_exports_every_declared_symbol():
+    lib = hip.load()
+    header = open(os.path.join(ROOT, "include", "rays_hip.h")).read()
+    import re
+    declared = set(re.findall(r"\b(rays_hip_\w+)\s*\(", header))
+    assert declared == set(hip.EXPORTED_SYMBOLS), declared ^ set(hip.EXPORTED_SYMBOLS)
+    for sym in declared:
+        getattr(lib, sym)
+    assert lib.rays_hip_sizeof_params() == C.sizeof(RaysParams)
+
+
+def test_c_abi_host_side_without_compute():
+    """Parameter validation, kernel lookup and the stop-flag table need no GPU."""
+    for name in GOLDEN_CASES:
+        g, nml, p = load_golden(name)
+        hip.check_params(p)
+        assert hip.kernel_name(p).startswith(("rk4_trace_kernel<", "sg_trace_kernel<"))
+    for code, text in STOP_FLAG_TEXT.items():
+        assert hip.stop_flag_text(code) == text
+    assert hip.stop_flag_text(2) == " nstep > nstep_max"  # leading blank (ray_tracing.f90:152)
+    g, nml, p = load_golden("cfg1_slab16_rk4")
+    from rays_amd.params import copy_params
+    q = copy_params(p)
+    q.nv = 8
+    with pytest.raises(hip.RaysHipError):
+        hip.check_params(q)
+    q = copy_params(p)
+    q.abi_version = 99
+    with pytest.raises(hip.RaysHipError):
+        hip.check_params(q)
+
+
+def test_product_fails_loudly_without_gpu():
+    lib = hip.load()
+    if lib.rays_hip_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    g, nml, p = load_golden("cfg1_slab16_rk4")
+    with pytest.raises(hip.RaysHipError):
+        hip.trace_host(p, g["rvec0"], g["rindex_vec0"])
