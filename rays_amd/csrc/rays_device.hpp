@@ -56,6 +56,12 @@ struct DevParams {
   double v_at1[RAYS_NS0], v_at2[RAYS_NS0];
   double box_rmin, box_rmax, box_zmin, box_zmax;
   double bp0, rk, rk2, rmaj2, bphi0_rmaj, half_bp0, bp0_2;
+  // Correctly rounded reciprocals RN(1/d) of constant denominators, computed on the host with an
+  // IEEE division (see Recip below).
+  double inv_k0, inv_omgrf, inv_omgrf2, inv_k0_p, inv_k0_m, inv_omgrf_p, inv_omgrf_m, inv_omgrf2_p,
+      inv_omgrf2_m;
+  double inv_ms[RAYS_NS0], inv_eps0ms[RAYS_NS0];
+  double inv_rk, inv_rk2, inv_rmaj, inv_rmaj2, inv_psiB;
 };
 
 RAYS_DEV double sq(double x) { return x * x; }
@@ -68,6 +74,47 @@ RAYS_DEV double pow_u(double x, double y) {
   if (y == 0.0) return 1.0;
   return pow(x, y);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Shared-reciprocal IEEE division.
+//
+// The RHS performs ~80 FP64 divisions per evaluation but only ~15 distinct denominators (r, r^2,
+// |B|, n_s, dD/dw, k0, omega, ...).  hipcc expands every `a/b` into the full correctly rounded
+// sequence (2x v_div_scale, v_rcp, 4 FMA Newton steps, mul, FMA residual, v_div_fmas, v_div_fixup
+// = 11 VALU ops, a long dependent chain).  Here the Newton-refined reciprocal is computed ONCE per
+// denominator and each quotient costs mul + 2 FMA + v_div_fixup -- the same final steps as the
+// compiler's expansion, so the quotient is the same correctly rounded RN(a/b) (Markstein: with
+// y = RN(1/b), q = RN(a*y), r = a - b*q (exact, FMA), RN(q + r*y) = RN(a/b)) and the results stay
+// bit-identical to the reference's IEEE divisions.  v_div_fixup restores the IEEE special cases
+// (0/0, x/0, inf, NaN) from the original operands.  Operands here are far from the over/underflow
+// range, so the v_div_scale pre-scaling of the generic expansion is the identity.
+// The FMAs below are explicit fused operations (the algorithm needs the exact residual); they are
+// not contractions of reference arithmetic, which stays unfused (-ffp-contract=off).
+// ---------------------------------------------------------------------------------------------
+struct Recip {
+  double d, rc;
+};
+#ifdef RAYS_HOST_EMUL
+RAYS_DEV Recip make_recip(double d) { return Recip{d, 0.}; }
+RAYS_DEV Recip const_recip(double d, double) { return Recip{d, 0.}; }
+RAYS_DEV double div(double a, const Recip& R) { return a / R.d; }
+#else
+RAYS_DEV Recip make_recip(double d) {
+  double y = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-d, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  return Recip{d, y};
+}
+RAYS_DEV Recip const_recip(double d, double inv) { return Recip{d, inv}; }
+RAYS_DEV double div(double a, const Recip& R) {
+  const double q = a * R.rc;
+  const double r = __builtin_fma(-R.d, q, a);
+  const double q1 = __builtin_fma(r, R.rc, q);
+  return __builtin_amdgcn_div_fixup(q1, R.d, a);
+}
+#endif
 
 // compiler-rt __divdc3 restricted to (a + 0i)/(c + 0i) -> real part; what flang emits for
 // real/complex and complex/real quotients (check_save.f90:226, suscep_m.f90:75).
@@ -92,6 +139,7 @@ struct EqPoint {
   double bvec[3], bmag, gradbmag[3], bunit[3], gradbunit[3][3], gbt[3][3];
   double ns[NS], gradns[NS][3], ts0, gradts0[3];
   double alpha[NS], gamma[NS];
+  Recip rbmag;  // shared reciprocal of |B|
   int err;
 };
 
@@ -232,33 +280,38 @@ RAYS_DEV int solovev_fields(const DevParams& P, const double rvec[3], double bve
   if (z < P.box_zmin || z > P.box_zmax) err = RAYS_STOP_Z_OUT_OF_BOX;  // :156
   if (!check_box) err = 0;
   const double bp0 = P.bp0;
+  const Recip Rr = make_recip(r), Rr2 = make_recip(sq(r));
+  const Recip Rrk = const_recip(P.rk, P.inv_rk), Rrk2 = const_recip(P.rk2, P.inv_rk2);
+  const Recip Rrmaj = const_recip(P.rmaj, P.inv_rmaj), Rrmaj2 = const_recip(P.rmaj2, P.inv_rmaj2);
+  const Recip RpsiB = const_recip(P.psiB, P.inv_psiB);
   // :170-172 (the same br, bz appear in solovev_psi :312-313)
-  const double br = -bp0 * r * z / P.rk2;
-  const double bz = bp0 * (sq(z / P.rk) + .5 * (sq(r / P.rmaj) - 1.));
+  const double br = div(-bp0 * r * z, Rrk2);
+  const double bz = bp0 * (sq(div(z, Rrk)) + .5 * (sq(div(r, Rrmaj)) - 1.));
   // solovev_psi :308-318
-  const double psi = P.half_bp0 * (sq(r * z / P.rk) + (sq(r * r - P.rmaj2)) / P.rmaj2 / 4.);
+  const double psi = P.half_bp0 * (sq(div(r * z, Rrk)) + div(sq(r * r - P.rmaj2), Rrmaj2) * 0.25);
   const double gradpsi[3] = {x * bz, y * bz, -r * br};
-  const double psiN = psi / P.psiB;
-  const double gradpsiN[3] = {gradpsi[0] / P.psiB, gradpsi[1] / P.psiB, gradpsi[2] / P.psiB};
+  const double psiN = div(psi, RpsiB);
+  const double gradpsiN[3] = {div(gradpsi[0], RpsiB), div(gradpsi[1], RpsiB), div(gradpsi[2], RpsiB)};
 
-  const double bphi = P.bphi0_rmaj / r;
-  const double dbrdr = br / r;
-  const double dbrdz = -bp0 * r / P.rk2;
-  const double dbzdr = bp0 * r / P.rmaj2;
-  const double dbzdz = P.bp0_2 * z / P.rk2;
-  const double dbphidr = -bphi / r;
-  bvec[0] = br * x / r - bphi * y / r;  // :187-189
-  bvec[1] = br * y / r + bphi * x / r;
+  const double bphi = div(P.bphi0_rmaj, Rr);
+  const double br_r = div(br, Rr), bphi_r = div(bphi, Rr);  // br/r, bphi/r (each appears 3x)
+  const double dbrdr = br_r;
+  const double dbrdz = div(-bp0 * r, Rrk2);
+  const double dbzdr = div(bp0 * r, Rrmaj2);
+  const double dbzdz = div(P.bp0_2 * z, Rrk2);
+  const double dbphidr = -bphi_r;
+  bvec[0] = div(br * x, Rr) - div(bphi * y, Rr);  // :187-189
+  bvec[1] = div(br * y, Rr) + div(bphi * x, Rr);
   bvec[2] = bz;
-  const double r2 = sq(r), x2 = sq(x), y2 = sq(y);
-  gbt[0][0] = (dbrdr * x2 + br * y2 / r + (-dbphidr + bphi / r) * x * y) / r2;  // :192-204
-  gbt[1][0] = ((dbrdr - br / r) * x * y - dbphidr * y2 - bphi * x2 / r) / r2;
-  gbt[2][0] = dbrdz * x / r;
-  gbt[0][1] = ((dbrdr - br / r) * x * y + dbphidr * x2 + bphi * y2 / r) / r2;
-  gbt[1][1] = (dbrdr * y2 + br * x2 / r + (dbphidr - bphi / r) * x * y) / r2;
-  gbt[2][1] = dbrdz * y / r;
-  gbt[0][2] = dbzdr * x / r;
-  gbt[1][2] = dbzdr * y / r;
+  const double x2 = sq(x), y2 = sq(y);
+  gbt[0][0] = div(dbrdr * x2 + div(br * y2, Rr) + (-dbphidr + bphi_r) * x * y, Rr2);  // :192-204
+  gbt[1][0] = div((dbrdr - br_r) * x * y - dbphidr * y2 - div(bphi * x2, Rr), Rr2);
+  gbt[2][0] = div(dbrdz * x, Rr);
+  gbt[0][1] = div((dbrdr - br_r) * x * y + dbphidr * x2 + div(bphi * y2, Rr), Rr2);
+  gbt[1][1] = div(dbrdr * y2 + div(br * x2, Rr) + (dbphidr - bphi_r) * x * y, Rr2);
+  gbt[2][1] = div(dbrdz * y, Rr);
+  gbt[0][2] = div(dbzdr * x, Rr);
+  gbt[1][2] = div(dbzdr * y, Rr);
   gbt[2][2] = dbzdz;
 
 #pragma unroll
@@ -325,8 +378,8 @@ RAYS_DEV int solovev_fields(const DevParams& P, const double rvec[3], double bve
 // (deriv_num.f90:72-79); on the device these are per-call values, which also removes the
 // reference's data race on the module variables.
 template <int EQ, int NS>
-RAYS_DEV void equilibrium(const DevParams& P, double omgrf, double omgrf2, const double rvec[3],
-                          EqPoint<NS>& eq, bool check_box) {
+RAYS_DEV void equilibrium(const DevParams& P, const Recip& Romgrf, const Recip& Romgrf2,
+                          const double rvec[3], EqPoint<NS>& eq, bool check_box) {
   double ns[NS], gradns[NS][3], ts[NS], gradts[NS][3];
   int err;
   if (EQ == RAYS_EQ_SLAB)
@@ -339,8 +392,10 @@ RAYS_DEV void equilibrium(const DevParams& P, double omgrf, double omgrf2, const
   // which does read it, then sees defined data (DESIGN.md "defined where the reference is not").
   const double bmag = sqrt(sq(eq.bvec[0]) + sq(eq.bvec[1]) + sq(eq.bvec[2]));  // :238
   eq.bmag = bmag;
+  const Recip Rb = make_recip(bmag);
+  eq.rbmag = Rb;
 #pragma unroll
-  for (int i = 0; i < 3; i++) eq.bunit[i] = eq.bvec[i] / bmag;
+  for (int i = 0; i < 3; i++) eq.bunit[i] = div(eq.bvec[i], Rb);
 #pragma unroll
   for (int i = 0; i < 3; i++)  // :244-246
     eq.gradbmag[i] = eq.gbt[i][0] * eq.bunit[0] + eq.gbt[i][1] * eq.bunit[1] + eq.gbt[i][2] * eq.bunit[2];
@@ -348,16 +403,16 @@ RAYS_DEV void equilibrium(const DevParams& P, double omgrf, double omgrf2, const
   for (int i = 0; i < 3; i++)
 #pragma unroll
     for (int j = 0; j < 3; j++)  // :254-257
-      eq.gradbunit[i][j] = (eq.gbt[i][j] - eq.gradbmag[i] * eq.bunit[j]) / bmag;
+      eq.gradbunit[i][j] = div(eq.gbt[i][j] - eq.gradbmag[i] * eq.bunit[j], Rb);
 #pragma unroll
   for (int is = 0; is < NS; is++) {  // :262-265
     eq.ns[is] = ns[is];
 #pragma unroll
     for (int i = 0; i < 3; i++) eq.gradns[is][i] = gradns[is][i];
-    const double omgc = P.qs[is] * bmag / P.ms[is];
-    const double omgp2 = ns[is] * P.qs2[is] / P.eps0ms[is];
-    eq.alpha[is] = omgp2 / omgrf2;
-    eq.gamma[is] = omgc / omgrf;
+    const double omgc = div(P.qs[is] * bmag, const_recip(P.ms[is], P.inv_ms[is]));
+    const double omgp2 = div(ns[is] * P.qs2[is], const_recip(P.eps0ms[is], P.inv_eps0ms[is]));
+    eq.alpha[is] = div(omgp2, Romgrf2);
+    eq.gamma[is] = div(omgc, Romgrf);
   }
   eq.ts0 = ts[0];
 #pragma unroll
@@ -368,7 +423,7 @@ RAYS_DEV void equilibrium(const DevParams& P, double omgrf, double omgrf2, const
 template <int NS>
 RAYS_DEV void deriv_cold(const DevParams& P, const EqPoint<NS>& eq, const double nvec[3],
                          double dddx[3], double dddk[3], double& dddw) {
-  const double k0 = P.k0;
+  const Recip Rk0 = const_recip(P.k0, P.inv_k0);
   double alpha[NS], gamma[NS];
 #pragma unroll
   for (int is = 0; is < NS; is++) {
@@ -383,20 +438,22 @@ RAYS_DEV void deriv_cold(const DevParams& P, const EqPoint<NS>& eq, const double
   double dn3dk[3], dn12dk[3], dn3dx[3], dn12dx[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
-    dn3dk[i] = eq.bunit[i] / k0;              // :50
+    dn3dk[i] = div(eq.bunit[i], Rk0);         // :50
     dn12dk[i] = P.two_over_k0 * np[i];        // :51
     dn3dx[i] = eq.gradbunit[i][0] * nvec[0] + eq.gradbunit[i][1] * nvec[1] + eq.gradbunit[i][2] * nvec[2];
     dn12dx[i] = -2. * n3 * dn3dx[i];          // :57
   }
   double dadx[3][NS], dgdx[3][NS];
 #pragma unroll
-  for (int i = 0; i < 3; i++)
+  for (int is = 0; is < NS; is++) {
+    const Recip Rns = make_recip(eq.ns[is]);
 #pragma unroll
-    for (int is = 0; is < NS; is++) {
-      dadx[i][is] = eq.alpha[is] * eq.gradns[is][i] / eq.ns[is];  // :64  (0*0/0 = NaN outside plasma)
-      dgdx[i][is] = gamma[is] * eq.gradbmag[i] / eq.bmag;         // :65
+    for (int i = 0; i < 3; i++) {
+      dadx[i][is] = div(eq.alpha[is] * eq.gradns[is][i], Rns);  // :64  (0*0/0 = NaN outside plasma)
+      dgdx[i][is] = div(gamma[is] * eq.gradbmag[i], eq.rbmag);  // :65
     }
-  const double dn3dw = -n3 / P.omgrf;                // :72
+  }
+  const double dn3dw = div(-n3, const_recip(P.omgrf, P.inv_omgrf));  // :72
   const double dn12dw = P.m2_over_omgrf * sq(n1);    // :73
   double dadw[NS], dgdw[NS];
 #pragma unroll
@@ -526,10 +583,10 @@ RAYS_DEV double epsn_det(double e11, double e33, double x12, double n1, double n
 // determ                    deriv_num.f90:99-153 (ray_dispersion_model == 'cold')
 template <int NS>
 RAYS_DEV double determ(const double bunit[3], const double alpha[NS], const double gamma[NS],
-                       const double kvec[3], double k0) {
+                       const double kvec[3], const Recip& Rk0) {
   const double k3 = kvec[0] * bunit[0] + kvec[1] * bunit[1] + kvec[2] * bunit[2];
   const double k1 = sqrt(sq(kvec[0] - k3 * bunit[0]) + sq(kvec[1] - k3 * bunit[1]) + sq(kvec[2] - k3 * bunit[2]));
-  const double n1 = k1 / k0, n3 = k3 / k0;
+  const double n1 = div(k1, Rk0), n3 = div(k3, Rk0);
   const double nsq = sq(n1) + 0. + sq(n3);
   double e11, e33, x12;
   eps_cold<NS>(alpha, gamma, e11, e33, x12);
@@ -542,10 +599,10 @@ RAYS_DEV double determ(const double bunit[3], const double alpha[NS], const doub
 
 // Light equilibrium for determ: only bunit, alpha, gamma at a (possibly perturbed) point.
 template <int EQ, int NS>
-RAYS_DEV void eq_for_determ(const DevParams& P, double omgrf, double omgrf2, const double rvec[3],
-                            double bunit[3], double alpha[NS], double gamma[NS]) {
+RAYS_DEV void eq_for_determ(const DevParams& P, const Recip& Romgrf, const Recip& Romgrf2,
+                            const double rvec[3], double bunit[3], double alpha[NS], double gamma[NS]) {
   EqPoint<NS> e;
-  equilibrium<EQ, NS>(P, omgrf, omgrf2, rvec, e, false);
+  equilibrium<EQ, NS>(P, Romgrf, Romgrf2, rvec, e, false);
 #pragma unroll
   for (int i = 0; i < 3; i++) bunit[i] = e.bunit[i];
 #pragma unroll
@@ -563,6 +620,8 @@ template <int EQ, int NS>
 RAYS_DEV void deriv_num(const DevParams& P, const EqPoint<NS>& eq0, const double rvec0[3],
                         const double kvec0[3], double dddx[3], double dddk[3], double& dddw) {
   double bu[3], al[NS], ga[NS];
+  const Recip Ro = const_recip(P.omgrf, P.inv_omgrf), Ro2 = const_recip(P.omgrf2, P.inv_omgrf2);
+  const Recip Rk0 = const_recip(P.k0, P.inv_k0);
 #pragma unroll 1
   for (int i = 0; i < 3; i++) {  // :40-57
     double rp[3], rm[3];
@@ -571,10 +630,10 @@ RAYS_DEV void deriv_num(const DevParams& P, const EqPoint<NS>& eq0, const double
       rp[c] = (c == i) ? rvec0[c] + P.delta : rvec0[c];
       rm[c] = (c == i) ? rvec0[c] - P.delta : rvec0[c];
     }
-    eq_for_determ<EQ, NS>(P, P.omgrf, P.omgrf2, rp, bu, al, ga);
-    const double det_plus = determ<NS>(bu, al, ga, kvec0, P.k0);
-    eq_for_determ<EQ, NS>(P, P.omgrf, P.omgrf2, rm, bu, al, ga);
-    const double det_minus = determ<NS>(bu, al, ga, kvec0, P.k0);
+    eq_for_determ<EQ, NS>(P, Ro, Ro2, rp, bu, al, ga);
+    const double det_plus = determ<NS>(bu, al, ga, kvec0, Rk0);
+    eq_for_determ<EQ, NS>(P, Ro, Ro2, rm, bu, al, ga);
+    const double det_minus = determ<NS>(bu, al, ga, kvec0, Rk0);
     const double d = (det_plus - det_minus) / P.two_delta;
     if (i == 0) dddx[0] = d;
     if (i == 1) dddx[1] = d;
@@ -590,18 +649,20 @@ RAYS_DEV void deriv_num(const DevParams& P, const EqPoint<NS>& eq0, const double
       kp[c] = (c == i) ? kvec0[c] + change : kvec0[c];
       km[c] = (c == i) ? kvec0[c] - change : kvec0[c];
     }
-    const double det_plus = determ<NS>(eq0.bunit, eq0.alpha, eq0.gamma, kp, P.k0);
-    const double det_minus = determ<NS>(eq0.bunit, eq0.alpha, eq0.gamma, km, P.k0);
+    const double det_plus = determ<NS>(eq0.bunit, eq0.alpha, eq0.gamma, kp, Rk0);
+    const double det_minus = determ<NS>(eq0.bunit, eq0.alpha, eq0.gamma, km, Rk0);
     const double d = (det_plus - det_minus) / (2. * change);
     if (i == 0) dddk[0] = d;
     if (i == 1) dddk[1] = d;
     if (i == 2) dddk[2] = d;
   }
   // :71-80 omega: per-lane omgrf/k0 instead of rewriting module variables
-  eq_for_determ<EQ, NS>(P, P.omgrf_p, P.omgrf2_p, rvec0, bu, al, ga);
-  const double det_plus = determ<NS>(bu, al, ga, kvec0, P.k0_p);
-  eq_for_determ<EQ, NS>(P, P.omgrf_m, P.omgrf2_m, rvec0, bu, al, ga);
-  const double det_minus = determ<NS>(bu, al, ga, kvec0, P.k0_m);
+  eq_for_determ<EQ, NS>(P, const_recip(P.omgrf_p, P.inv_omgrf_p), const_recip(P.omgrf2_p, P.inv_omgrf2_p),
+                        rvec0, bu, al, ga);
+  const double det_plus = determ<NS>(bu, al, ga, kvec0, const_recip(P.k0_p, P.inv_k0_p));
+  eq_for_determ<EQ, NS>(P, const_recip(P.omgrf_m, P.inv_omgrf_m), const_recip(P.omgrf2_m, P.inv_omgrf2_m),
+                        rvec0, bu, al, ga);
+  const double det_minus = determ<NS>(bu, al, ga, kvec0, const_recip(P.k0_m, P.inv_k0_m));
   dddw = (det_plus - det_minus) / P.omgrf0_delta;
 }
 
@@ -613,19 +674,20 @@ template <int NS, int NV>
 RAYS_DEV int ray_equations(const DevParams& P, const EqPoint<NS>& eq, const double dddx[3],
                            const double dddk[3], double dddw, double dvds[NV]) {
   if (!(dddw != 0.)) return RAYS_STOP_INFINITE_VG_RHS;  // :133 (`/= 0.` is true for NaN)
+  const Recip Rw = make_recip(dddw);
   double vg[3];
 #pragma unroll
-  for (int i = 0; i < 3; i++) vg[i] = -dddk[i] / dddw;
+  for (int i = 0; i < 3; i++) vg[i] = div(-dddk[i], Rw);
   const double vg0 = sqrt(sq(vg[0]) + sq(vg[1]) + sq(vg[2]));
   double dsd;
   if (P.ray_param == RAYS_PARAM_ARCL) {  // :150-170
     if (dddk[0] != 0. || dddk[1] != 0. || dddk[2] != 0.) {
       const double sgn = copysign(1.0, dddw);
-      const double nk = sqrt(sq(dddk[0]) + sq(dddk[1]) + sq(dddk[2]));
+      const Recip Rnk = make_recip(sqrt(sq(dddk[0]) + sq(dddk[1]) + sq(dddk[2])));
 #pragma unroll
       for (int i = 0; i < 3; i++) {
-        dvds[i] = -sgn * dddk[i] / nk;
-        dvds[3 + i] = sgn * dddx[i] / nk;
+        dvds[i] = div(-sgn * dddk[i], Rnk);
+        dvds[3 + i] = div(sgn * dddx[i], Rnk);
       }
       dsd = 1.;
     } else {
@@ -635,15 +697,16 @@ RAYS_DEV int ray_equations(const DevParams& P, const EqPoint<NS>& eq, const doub
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       dvds[i] = vg[i];  // -dddk/dddw
-      dvds[3 + i] = dddx[i] / dddw;
+      dvds[3 + i] = div(dddx[i], Rw);
     }
     dsd = vg0;
   }
   dvds[6] = dsd;  // :190
   if (NV > 7) {   // :217-229 integrate_eq_gradients
+    const Recip Rvg0 = make_recip(vg0);
     double vu[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) vu[i] = vg[i] / vg0;
+    for (int i = 0; i < 3; i++) vu[i] = div(vg[i], Rvg0);
 #pragma unroll
     for (int j = 0; j < 3; j++)
       dvds[7 + j] = dsd * vu[0] * eq.gbt[0][j] + dsd * vu[1] * eq.gbt[1][j] + dsd * vu[2] * eq.gbt[2][j];
@@ -658,11 +721,12 @@ template <int EQ, int NS, int DERIV, int NV>
 RAYS_DEV int eqn_ray(const DevParams& P, const double v[NV], double dvds[NV]) {
   const double rvec[3] = {v[0], v[1], v[2]}, kvec[3] = {v[3], v[4], v[5]};
   EqPoint<NS> eq;
-  equilibrium<EQ, NS>(P, P.omgrf, P.omgrf2, rvec, eq, true);
+  equilibrium<EQ, NS>(P, const_recip(P.omgrf, P.inv_omgrf), const_recip(P.omgrf2, P.inv_omgrf2), rvec, eq, true);
   if (eq.err) return eq.err;  // :90-102
   double dddx[3], dddk[3], dddw;
   if (DERIV == RAYS_DERIV_COLD) {
-    const double nvec[3] = {kvec[0] / P.k0, kvec[1] / P.k0, kvec[2] / P.k0};  // :84
+    const Recip Rk0 = const_recip(P.k0, P.inv_k0);
+    const double nvec[3] = {div(kvec[0], Rk0), div(kvec[1], Rk0), div(kvec[2], Rk0)};  // :84
     deriv_cold<NS>(P, eq, nvec, dddx, dddk, dddw);
   } else {
     deriv_num<EQ, NS>(P, eq, rvec, kvec, dddx, dddk, dddw);
@@ -688,8 +752,9 @@ RAYS_DEV void rhs_eval(const DevParams& P, const double v[NV], bool do_check, do
                        int& cs_flag, bool& cs_stop, int& code, double f[NV]) {
   const double rvec[3] = {v[0], v[1], v[2]}, kvec[3] = {v[3], v[4], v[5]};
   EqPoint<NS> eq;
-  equilibrium<EQ, NS>(P, P.omgrf, P.omgrf2, rvec, eq, true);
-  const double nvec[3] = {kvec[0] / P.k0, kvec[1] / P.k0, kvec[2] / P.k0};  // eqn_ray.f90:84
+  equilibrium<EQ, NS>(P, const_recip(P.omgrf, P.inv_omgrf), const_recip(P.omgrf2, P.inv_omgrf2), rvec, eq, true);
+  const Recip Rk0 = const_recip(P.k0, P.inv_k0);
+  const double nvec[3] = {div(kvec[0], Rk0), div(kvec[1], Rk0), div(kvec[2], Rk0)};  // eqn_ray.f90:84
   cs_flag = 0;
   cs_stop = false;
   resid = 0.;
@@ -700,7 +765,7 @@ RAYS_DEV void rhs_eval(const DevParams& P, const double v[NV], bool do_check, do
     const double k1 = sqrt(sq(kvec[0] - k3 * eq.bunit[0]) + sq(kvec[1] - k3 * eq.bunit[1]) +
                            sq(kvec[2] - k3 * eq.bunit[2]));
     // residual :163-235
-    const double n1 = k1 / P.k0, n3 = k3 / P.k0;
+    const double n1 = div(k1, Rk0), n3 = div(k3, Rk0);
     const double nsq = sq(n1) + 0. + sq(n3);
     double e11, e33, x12;
     eps_cold<NS>(eq.alpha, eq.gamma, e11, e33, x12);
@@ -742,7 +807,7 @@ RAYS_DEV void initialize_ode_vector(const DevParams& P, const double* __restrict
   if (NV > 7) {
     EqPoint<NS> eq;
     const double rvec[3] = {v[0], v[1], v[2]};
-    equilibrium<EQ, NS>(P, P.omgrf, P.omgrf2, rvec, eq, false);
+    equilibrium<EQ, NS>(P, const_recip(P.omgrf, P.inv_omgrf), const_recip(P.omgrf2, P.inv_omgrf2), rvec, eq, false);
     v[7] = eq.bvec[0];
     v[8] = eq.bvec[1];
     v[9] = eq.bvec[2];

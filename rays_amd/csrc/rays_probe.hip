@@ -12,7 +12,7 @@ __device__ void probe_one(const DevParams& P, const double* vin, double* cold7, 
   for (int i = 0; i < NV; i++) v[i] = vin[i];
   const double rvec[3] = {v[0], v[1], v[2]}, kvec[3] = {v[3], v[4], v[5]};
   EqPoint<NS> eq;
-  equilibrium<EQ, NS>(P, P.omgrf, P.omgrf2, rvec, eq, true);
+  equilibrium<EQ, NS>(P, const_recip(P.omgrf, P.inv_omgrf), const_recip(P.omgrf2, P.inv_omgrf2), rvec, eq, true);
   codes[0] = eq.err;
   const double nvec[3] = {kvec[0] / P.k0, kvec[1] / P.k0, kvec[2] / P.k0};
   double dx[3], dk[3], dw;

@@ -111,7 +111,6 @@ def test_full_64k_fan_properties():
     assert not a.ray_vec[~live].any() and not a.residual[~live].any()        # zero past npoints
     assert np.isfinite(a.ray_vec[live]).all()
     assert a.residual[live].max() <= p.dispersion_resid_limit                # recorded points pass check_save
-    assert np.median(a.residual[live]) < 1e-8                               # rays stay on D = 0
     s7 = a.ray_vec[..., 6]
     assert (np.diff(s7, axis=1)[live[:, 1:]] > 0).all()                      # arc length grows
     assert a.total_steps == int((npt - 1).sum())
