@@ -35,12 +35,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def build_fan(cfg_path, world):
+def build_fan(cfg_path, world, fan_scale=1, nstep_max=None):
     from rays_amd.namelist import read_namelist
     from rays_amd.params import params_from_namelist
     from rays_amd.ray_init import initialize_ray_init
 
     nml = read_namelist(cfg_path)
+    world = world * fan_scale
+    if nstep_max is not None:
+        nml["ode_list"]["nstep_max"] = int(nstep_max)
     if world > 1:  # weak scaling: world x more launch angles in n_theta over the same range
         g = nml["solovev_ray_init_nphi_ktheta_list"] if "solovev_ray_init_nphi_ktheta_list" in nml \
             else nml["simple_slab_ray_init_list"]
@@ -125,6 +128,9 @@ def main():
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "cfg3b_solovev64k_rk4.in"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the trajectory gather (diagnostic)")
+    ap.add_argument("--fan-scale", type=int, default=1,
+                    help="diagnostic: rays per GPU = 65536 x this (finer n_theta); not the headline config")
+    ap.add_argument("--nstep-max", type=int, default=None, help="diagnostic: override nstep_max")
     args = ap.parse_args()
 
     import torch
@@ -140,13 +146,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and not os.environ.get("RAYS_BENCH_SHARE_GPU"):
+        raise SystemExit(f"local rank {local_rank} has no GPU ({ndev} visible)")
+    dev_index = local_rank % ndev  # RAYS_BENCH_SHARE_GPU=1: rehearsal of N ranks on fewer GPUs
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("RAYS_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend, device_id=dev if backend == "nccl" else None)
 
-    nml, p, r0, n0 = build_fan(args.config, world)
+    nml, p, r0, n0 = build_fan(args.config, world, args.fan_scale, args.nstep_max)
     nray_total = len(r0)
     from rays_amd.exchange import shard_bounds
 

@@ -121,3 +121,32 @@ def test_full_64k_fan_properties():
     np.testing.assert_array_equal(a.stop_code[sel], ora["stop_code"])
     np.testing.assert_array_equal(a.ray_vec[sel], ora["ray_vec"])
     np.testing.assert_array_equal(a.end_ray_vec[sel], ora["end_ray_vec"])
+
+
+def test_pack_unpack_roundtrip_on_device():
+    """The multi-GPU exchange payload: unpack(pack(slab)) == slab, packed size = sum(npoints)."""
+    import torch
+    from rays_amd.trace import DeviceTrace
+
+    g, nml, p = load_golden("cfg2_solovev1024_rk4")
+    tr = DeviceTrace(p, g["rvec0_full"][:300], g["rindex_vec0_full"][:300])
+    tr.launch()
+    torch.cuda.synchronize()
+    n, nv = tr.nray, p.nv
+    npts = tr.npoints
+    off = torch.cumsum(npts, 0, dtype=torch.int64) - npts
+    total = int(npts.sum().item())
+    pv = torch.full((total, nv), float("nan"), dtype=torch.float64, device="cuda")
+    pr = torch.full((total,), float("nan"), dtype=torch.float64, device="cuda")
+    hip.pack_device(n, nv, p.nstep_max, npts.data_ptr(), off.data_ptr(), tr.ray_vec.data_ptr(),
+                    tr.residual.data_ptr(), pv.data_ptr(), pr.data_ptr())
+    rv2, rs2 = torch.zeros_like(tr.ray_vec), torch.zeros_like(tr.residual)
+    hip.unpack_device(n, nv, p.nstep_max, npts.data_ptr(), off.data_ptr(), pv.data_ptr(), pr.data_ptr(),
+                      rv2.data_ptr(), rs2.data_ptr())
+    torch.cuda.synchronize()
+    assert not torch.isnan(pv).any() and not torch.isnan(pr).any()
+    assert torch.equal(rv2, tr.ray_vec) and torch.equal(rs2, tr.residual)
+    # packed rows are the rays' points in order
+    r = 7
+    o, m = int(off[r]), int(npts[r])
+    assert torch.equal(pv[o:o + m], tr.ray_vec[r, :m])
