@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "cfg3b_solovev64k_rk4.in"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the trajectory gather (diagnostic)")
+    ap.add_argument("--verify-gather", action="store_true",
+                    help="N>1 diagnostic: rank 0 re-traces the whole fan and checks the gathered arrays")
     ap.add_argument("--fan-scale", type=int, default=1,
                     help="diagnostic: rays per GPU = 65536 x this (finer n_theta); not the headline config")
     ap.add_argument("--nstep-max", type=int, default=None, help="diagnostic: override nstep_max")
@@ -181,7 +183,9 @@ def main():
         tg.prepare(tr.npoints)
 
         def gather():
-            tg.gather(tr.ray_vec, tr.residual, tr.npoints, tr.stop_code)
+            # starts this pass's exchange and completes the previous one: the RCCL transfers of
+            # pass i overlap the trace of pass i+1; barrier() below drains the last one
+            tg.gather_async(tr.ray_vec, tr.residual, tr.npoints, tr.stop_code)
 
     def step(ev=None):
         if ev is not None:
@@ -193,6 +197,8 @@ def main():
             gather()
 
     def barrier():
+        if gather is not None:
+            tg.finish()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -220,6 +226,15 @@ def main():
     # the timed passes must have reproduced the first pass (deterministic kernels)
     assert int(torch.clamp(tr.npoints.to(torch.int64) - 1, min=0).sum().item()) == steps_local
 
+    if rank == 0 and gather is not None and args.verify_gather:
+        full = DeviceTrace(p, r0, n0, device=dev)
+        full.launch()
+        torch.cuda.synchronize()
+        ok = (torch.equal(full.ray_vec, tg.ray_vec) and torch.equal(full.residual, tg.residual)
+              and torch.equal(full.npoints, tg.npoints) and torch.equal(full.stop_code, tg.stop_code))
+        print(f"[bench] gather verification: {'OK' if ok else 'MISMATCH'}", file=sys.stderr)
+        if not ok:
+            raise SystemExit("gathered trajectories differ from a single-GPU trace of the same fan")
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = total_steps / (elapsed / args.steps)

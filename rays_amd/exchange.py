@@ -61,7 +61,6 @@ class TrajectoryGather:
         n_local = self.nrays[self.rank]
         f64, i64, i32 = torch.float64, torch.int64, torch.int32
         self.offsets = torch.zeros(n_local, dtype=i64, device=device)
-        self._cap = 0
         self.packed_vec = self.packed_res = None
         if self.rank == 0:
             npt = nstep_max + 1
@@ -70,72 +69,118 @@ class TrajectoryGather:
             self.npoints = torch.zeros(nray_total, dtype=i32, device=device)
             self.stop_code = torch.zeros(nray_total, dtype=i32, device=device)
             self._r_off = [torch.zeros(n, dtype=i64, device=device) for n in self.nrays]
-            self._r_vec: List[Optional[object]] = [None] * self.world
-            self._r_res: List[Optional[object]] = [None] * self.world
         self._counts = None
+        self._pending = None
+        self._buf = 0
 
     def _stream(self):
         t = self.torch
         return t.cuda.current_stream().cuda_stream if self.device.type == "cuda" else 0
 
     def prepare(self, npoints_local):
-        """Exchange per-rank point counts and size the buffers (once per fan; not per step)."""
+        """Exchange per-rank point counts and size the buffers (once per fan; not per step).
+        Send/receive staging is double-buffered so the exchange of pass i can overlap the trace of
+        pass i+1 (gather_async)."""
         t, dist = self.torch, self.dist
         mine = t.tensor([int(npoints_local.to(t.int64).sum().item())], dtype=t.int64, device=self.device)
         counts = [t.zeros(1, dtype=t.int64, device=self.device) for _ in range(self.world)]
         dist.all_gather(counts, mine, group=self.group)
         self._counts = [int(c.item()) for c in counts]
         cap = max(self._counts[self.rank], 1)
-        self.packed_vec = t.empty((cap, self.nv), dtype=t.float64, device=self.device)
-        self.packed_res = t.empty(cap, dtype=t.float64, device=self.device)
+        n_local = self.nrays[self.rank]
+        f64, i32 = t.float64, t.int32
+        self._send = [dict(vec=t.empty((cap, self.nv), dtype=f64, device=self.device),
+                           res=t.empty(cap, dtype=f64, device=self.device),
+                           npoints=t.zeros(n_local, dtype=i32, device=self.device),
+                           stop=t.zeros(n_local, dtype=i32, device=self.device)) for _ in range(2)]
+        self.packed_vec, self.packed_res = self._send[0]["vec"], self._send[0]["res"]
         if self.rank == 0:
-            for r in range(1, self.world):
-                c = max(self._counts[r], 1)
-                self._r_vec[r] = t.empty((c, self.nv), dtype=t.float64, device=self.device)
-                self._r_res[r] = t.empty(c, dtype=t.float64, device=self.device)
+            self._recv = []
+            for _ in range(2):
+                slot = {}
+                for r in range(1, self.world):
+                    c = max(self._counts[r], 1)
+                    slot[r] = dict(vec=t.empty((c, self.nv), dtype=f64, device=self.device),
+                                   res=t.empty(c, dtype=f64, device=self.device),
+                                   npoints=t.zeros(self.nrays[r], dtype=i32, device=self.device),
+                                   stop=t.zeros(self.nrays[r], dtype=i32, device=self.device))
+                self._recv.append(slot)
+        self._pending = None
+        self._buf = 0
 
-    def gather(self, ray_vec, residual, npoints, stop_code):
+    # ---- asynchronous form: start the exchange of this pass, complete the previous one -------
+    def gather_async(self, ray_vec, residual, npoints, stop_code):
+        """Pack this pass's slab and start its exchange; complete the previous pass's exchange.
+        The caller launches the next trace right after: RCCL's stream carries the transfers while
+        the compute stream runs the next pass.  Call finish() after the last pass."""
         t, dist = self.torch, self.dist
         if self._counts is None:
             self.prepare(npoints)
         stream = self._stream()
+        b = self._buf
         n_local = self.nrays[self.rank]
+        snd = self._send[b]
         t.cumsum(npoints, 0, dtype=t.int64, out=self.offsets)
-        self.offsets.sub_(npoints)  # exclusive prefix sum
+        self.offsets.sub_(npoints)
         self.pack(n_local, self.nv, self.nstep_max, npoints, self.offsets, ray_vec, residual,
-                  self.packed_vec, self.packed_res, stream)
+                  snd["vec"], snd["res"], stream)
+        snd["npoints"].copy_(npoints)
+        snd["stop"].copy_(stop_code)
+        self._complete()  # previous pass (its buffers are the other slot)
+        works = []
         if self.rank == 0:
             lo, hi = self.bounds[0]
-            ops = []
-            for r in range(1, self.world):
-                b0, b1 = self.bounds[r]
-                if b1 == b0:
-                    continue
-                ops += [dist.P2POp(dist.irecv, self.npoints[b0:b1], r, self.group),
-                        dist.P2POp(dist.irecv, self.stop_code[b0:b1], r, self.group),
-                        dist.P2POp(dist.irecv, self._r_vec[r], r, self.group),
-                        dist.P2POp(dist.irecv, self._r_res[r], r, self.group)]
-            works = dist.batch_isend_irecv(ops) if ops else []
-            # own slab is already in the padded layout
             self.ray_vec[lo:hi].copy_(ray_vec)
             self.residual[lo:hi].copy_(residual)
             self.npoints[lo:hi].copy_(npoints)
             self.stop_code[lo:hi].copy_(stop_code)
-            for w in works:
-                w.wait()
+            ops = []
+            for r in range(1, self.world):
+                if self.nrays[r] == 0:
+                    continue
+                rc = self._recv[b][r]
+                ops += [dist.P2POp(dist.irecv, rc["npoints"], r, self.group),
+                        dist.P2POp(dist.irecv, rc["stop"], r, self.group),
+                        dist.P2POp(dist.irecv, rc["vec"], r, self.group),
+                        dist.P2POp(dist.irecv, rc["res"], r, self.group)]
+            works = dist.batch_isend_irecv(ops) if ops else []
+        elif n_local > 0:
+            ops = [dist.P2POp(dist.isend, snd["npoints"], 0, self.group),
+                   dist.P2POp(dist.isend, snd["stop"], 0, self.group),
+                   dist.P2POp(dist.isend, snd["vec"], 0, self.group),
+                   dist.P2POp(dist.isend, snd["res"], 0, self.group)]
+            works = dist.batch_isend_irecv(ops)
+        self._pending = (b, works)
+        self._buf = 1 - b
+
+    def _complete(self):
+        if self._pending is None:
+            return
+        t = self.torch
+        b, works = self._pending
+        self._pending = None
+        for w in works:
+            w.wait()
+        if self.rank == 0:
+            stream = self._stream()
             for r in range(1, self.world):
                 b0, b1 = self.bounds[r]
                 if b1 == b0:
                     continue
-                npts = self.npoints[b0:b1]
-                t.cumsum(npts, 0, dtype=t.int64, out=self._r_off[r])
-                self._r_off[r].sub_(npts)
-                self.unpack(b1 - b0, self.nv, self.nstep_max, npts, self._r_off[r], self._r_vec[r],
-                            self._r_res[r], self.ray_vec[b0:b1], self.residual[b0:b1], stream)
-        elif n_local > 0:
-            ops = [dist.P2POp(dist.isend, npoints, 0, self.group),
-                   dist.P2POp(dist.isend, stop_code, 0, self.group),
-                   dist.P2POp(dist.isend, self.packed_vec, 0, self.group),
-                   dist.P2POp(dist.isend, self.packed_res, 0, self.group)]
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+                rc = self._recv[b][r]
+                self.npoints[b0:b1].copy_(rc["npoints"])
+                self.stop_code[b0:b1].copy_(rc["stop"])
+                t.cumsum(rc["npoints"], 0, dtype=t.int64, out=self._r_off[r])
+                self._r_off[r].sub_(rc["npoints"])
+                # the peer's slab may hold longer rays from an earlier pass only if the fan changed;
+                # passes over the same fan rewrite the same entries, so no re-zeroing is needed
+                self.unpack(b1 - b0, self.nv, self.nstep_max, rc["npoints"], self._r_off[r], rc["vec"],
+                            rc["res"], self.ray_vec[b0:b1], self.residual[b0:b1], stream)
+
+    def finish(self):
+        self._complete()
+
+    def gather(self, ray_vec, residual, npoints, stop_code):
+        """Synchronous form: returns with rank 0's global arrays complete (stream-ordered)."""
+        self.gather_async(ray_vec, residual, npoints, stop_code)
+        self.finish()

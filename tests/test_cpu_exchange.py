@@ -40,9 +40,12 @@ def _worker(rank, world, port, q):
         lo, hi = shard_bounds(len(r0), world, rank)
         out = oracle_lib.trace(p, r0[lo:hi], n0[lo:hi], nthreads=1)
         tg = TrajectoryGather(len(r0), p.nv, p.nstep_max, torch.device("cpu"), pack=_pack, unpack=_unpack)
-        for _ in range(2):  # twice: buffers are reused per step
-            tg.gather(torch.from_numpy(out["ray_vec"]), torch.from_numpy(out["residual"]),
-                      torch.from_numpy(out["npoints"]), torch.from_numpy(out["stop_code"]))
+        args = (torch.from_numpy(out["ray_vec"]), torch.from_numpy(out["residual"]),
+                torch.from_numpy(out["npoints"]), torch.from_numpy(out["stop_code"]))
+        tg.gather(*args)                 # synchronous form
+        for _ in range(3):               # pipelined form: buffers alternate, last pass drained by finish()
+            tg.gather_async(*args)
+        tg.finish()
         if rank == 0:
             full = oracle_lib.trace(p, r0, n0, nthreads=1)
             ok = (np.array_equal(tg.ray_vec.numpy(), full["ray_vec"])
