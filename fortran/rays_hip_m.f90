@@ -11,7 +11,7 @@
     use, intrinsic :: iso_c_binding
     implicit none
 
-    integer(c_int), parameter :: RAYS_ABI_VERSION = 1
+    integer(c_int), parameter :: RAYS_ABI_VERSION = 2
     integer, parameter :: RAYS_NS0 = 6   ! species_m nspec0 + 1
 
     ! selectors
@@ -19,6 +19,7 @@
     integer(c_int32_t), parameter :: RAYS_DERIV_COLD = 0, RAYS_DERIV_NUM = 1
     integer(c_int32_t), parameter :: RAYS_PARAM_ARCL = 0, RAYS_PARAM_TIME = 1
     integer(c_int32_t), parameter :: RAYS_EQ_SLAB = 0, RAYS_EQ_SOLOVEV = 1
+    integer(c_int32_t), parameter :: RAYS_DAMP_NONE = 0, RAYS_DAMP_FUND_ECH = 1
 
     type, bind(C) :: rays_slab_params_t
         integer(c_int32_t) :: bx_prof_model, by_prof_model, bz_prof_model, dens_prof_model
@@ -59,6 +60,8 @@
         real(c_double) :: eta(RAYS_NS0)
         type(rays_slab_params_t) :: slab
         type(rays_solovev_params_t) :: solovev
+        integer(c_int32_t) :: damping_model, multi_spec_damping
+        real(c_double) :: total_damping_limit
     end type rays_params_t
 
     interface
@@ -82,6 +85,14 @@
           import :: c_int, c_ptr
           integer(c_int), value :: stop_code
        end function rays_hip_stop_flag_text
+
+       integer(c_int) function rays_hip_set_zfun_table(fspl_re, nx, x_min, x_max) &
+                    & bind(C, name='rays_hip_set_zfun_table')
+          import :: c_int, c_double
+          real(c_double), intent(in) :: fspl_re(4,*)
+          integer(c_int), value :: nx
+          real(c_double), value :: x_min, x_max
+       end function rays_hip_set_zfun_table
 
        integer(c_int) function rays_hip_check_params(p) bind(C, name='rays_hip_check_params')
           import :: c_int, rays_params_t

@@ -15,7 +15,8 @@
     use diagnostics_m, only : message, text_message, integrate_eq_gradients
     use species_m, only : nspec, qs, ms, n0s, t0s, eta
     use rf_m, only : omgrf, k0, ray_param, ray_dispersion_model, dispersion_resid_limit
-    use damping_m, only : damping_model, multi_spec_damping
+    use damping_m, only : damping_model, multi_spec_damping, total_damping_limit
+    use zfunctions_m, only : fsplRe, zf_nx => nx, x_grid_min, x_grid_max
     use equilibrium_m, only : equilib_model
     use slab_eq_m, only : s_xmin => xmin, s_xmax => xmax, s_ymin => ymin, s_ymax => ymax, &
          & s_zmin => zmin, s_zmax => zmax, s_rmaj => rmaj, s_rmin => rmin, s_x0 => x0, &
@@ -90,9 +91,19 @@
           write(0,*) 'EQN_RAY: invalid ray parameter = ', ray_param; stop 1
     end select
     if (trim(ray_dispersion_model) /= 'cold') stop 'check_save: unimplemented ray_dispersion_model'
-    if (trim(damping_model) /= 'no_damp' .or. multi_spec_damping) then
-       write(0,*) 'trace_rays (HIP): damping_model /= no_damp is not on the device path yet'; stop 1
-    end if
+    select case (trim(damping_model))
+       case ('no_damp');       p%damping_model = RAYS_DAMP_NONE
+       case ('damp_fund_ECH'); p%damping_model = RAYS_DAMP_FUND_ECH
+          ! the Z-function spline table built by initialize_damping_m (zfunctions_m.f90:436-466)
+          if (rays_hip_set_zfun_table(fsplRe, int(zf_nx, c_int), x_grid_min, x_grid_max) /= 0) then
+             call last_error_string(msg)
+             write(0,*) 'trace_rays (HIP): ', trim(msg) ; stop 1
+          end if
+       case default
+          write (*, *) 'damping: Unimplemented damping model ', trim(damping_model); stop 1
+    end select
+    p%multi_spec_damping = merge(1, 0, multi_spec_damping)
+    p%total_damping_limit = total_damping_limit
 
     p%ds = ds ; p%s_max = s_max
     p%omgrf = omgrf ; p%k0 = k0 ; p%clight = clight ; p%eps0 = eps0

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define RAYS_ABI_VERSION 1
+#define RAYS_ABI_VERSION 2
 #define RAYS_NSPEC0 5 /* species_m.f90:25  nspec0; arrays are dimensioned 0:nspec0 */
 #define RAYS_NS0 (RAYS_NSPEC0 + 1)
 
@@ -44,6 +44,7 @@ enum { RAYS_ODE_RK4 = 0, RAYS_ODE_SG = 1 };           /* ode_m.f90:238  'RK4_ODE
 enum { RAYS_DERIV_COLD = 0, RAYS_DERIV_NUM = 1 };     /* eqn_ray.f90:106 'cold' | 'numerical'  */
 enum { RAYS_PARAM_ARCL = 0, RAYS_PARAM_TIME = 1 };    /* eqn_ray.f90:148 'arcl' | 'time'       */
 enum { RAYS_EQ_SLAB = 0, RAYS_EQ_SOLOVEV = 1 };       /* equilibrium_m.f90:177                 */
+enum { RAYS_DAMP_NONE = 0, RAYS_DAMP_FUND_ECH = 1 };  /* damping_m.f90:94-101 'no_damp' | 'damp_fund_ECH' */
 
 /* slab_eq_m.f90:172-300 profile-model strings */
 enum { RAYS_SLAB_BX_ZERO = 0 };
@@ -110,7 +111,7 @@ typedef struct rays_solovev_params {
 /* ---- everything trace_rays reads from module state ----------------------- */
 typedef struct rays_params {
   int32_t abi_version;  /* RAYS_ABI_VERSION */
-  int32_t nv;           /* ode_m.f90:160-173: 7, +5 with integrate_eq_gradients */
+  int32_t nv;           /* ode_m.f90:160-173: 7, +1 with damping, +5 with integrate_eq_gradients */
   int32_t nspec;        /* species_m.f90:27 number of ion species (electrons are species 0) */
   int32_t nstep_max;    /* ode_m.f90:104 */
   int32_t ode_solver;   /* RAYS_ODE_* */
@@ -129,6 +130,10 @@ typedef struct rays_params {
   double eta[RAYS_NS0];                /* species_m.f90:73 */
   rays_slab_params_t slab;
   rays_solovev_params_t solovev;
+  /* damping_m.f90:30-40 (appended in ABI version 2) */
+  int32_t damping_model;      /* RAYS_DAMP_* */
+  int32_t multi_spec_damping; /* must be 0 on the device path */
+  double total_damping_limit; /* damping_m.f90:38 */
 } rays_params_t;
 
 /* ---- library control ----------------------------------------------------------------------- */
@@ -144,6 +149,12 @@ int rays_hip_sizeof_params(void);
 int rays_hip_last_error(char* buf, int len);
 /* Reference ode_stop_flag text for a stop code (e.g. " nstep > nstep_max"); "" if unknown. */
 const char* rays_hip_stop_flag_text(int stop_code);
+/* Z-function spline table for damping_model = 'damp_fund_ECH' (zfunctions_m.f90:436-466): the host
+ * owns the table (the reference builds it in initialize_spline_coeffs); fspl_re is the PPPL-pspline
+ * compact cubic spline fsplRe(4, nx) in Fortran order == C [nx][4], on the uniform grid
+ * x_min .. x_max.  The library copies it; it must be set before tracing with damping. */
+int rays_hip_set_zfun_table(const double* fspl_re, int nx, double x_min, double x_max);
+
 /* Validates a parameter block exactly as the reference's `stop 1` configuration checks would;
  * 0 if the device path supports it. */
 int rays_hip_check_params(const rays_params_t* p);

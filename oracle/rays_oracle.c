@@ -638,6 +638,113 @@ static void deriv_num(const rays_params_t* P, rf_ctx rf0, const eq_point* eq0, c
 }
 
 /* --------------------------------------------------------------------------------------------
+ * Z function of a real argument by cubic spline: zfun_real_arg_spline_D / zfun0_real_arg_D
+ * (math_functions_lib/zfunctions_m.f90:351-432) with cspeval/cspevx/cspevfn on a uniform grid
+ * (splines_lib/cspeval.f90).  The table fsplRe(4,nx) is built by the host
+ * (initialize_spline_coeffs, :436-466) and handed over with rays_oracle_set_zfun_table.
+ * ------------------------------------------------------------------------------------------ */
+static int zf_nx = 0;
+static double zf_xmin = 0., zf_xmax = 0.;
+static double* zf_fspl = NULL; /* [nx][4] */
+
+int rays_oracle_set_zfun_table(const double* fspl_re, int nx, double x_min, double x_max) {
+  free(zf_fspl);
+  zf_fspl = (double*)malloc(sizeof(double) * 4 * (size_t)nx);
+  if (!zf_fspl) return 1;
+  memcpy(zf_fspl, fspl_re, sizeof(double) * 4 * (size_t)nx);
+  zf_nx = nx;
+  zf_xmin = x_min;
+  zf_xmax = x_max;
+  return 0;
+}
+
+static inline double zf_x(int i) { /* x_grid(i), 1-based (zfunctions_m.f90:444) */
+  return zf_xmin + (double)(i - 1) * (zf_xmax - zf_xmin) / (double)(zf_nx - 1);
+}
+
+static cplx zfun_real_arg_spline(double z) {
+  const double spline_range = 10.0;
+  double re;
+  if (fabs(z) <= spline_range) {
+    /* cspevx, ilinx = 1 (cspeval.f90:138-146) */
+    const int nxm = zf_nx - 1;
+    const double x1 = zf_x(1), xn = zf_x(zf_nx);
+    int ii = (int)(1 + nxm * (z - x1) / (xn - x1));
+    int i = ii < nxm ? ii : nxm;
+    if (z < zf_x(i)) i = i - 1;
+    else if (z > zf_x(i + 1)) i = i + 1;
+    const double dx = z - zf_x(i);
+    const double* f = zf_fspl + 4 * (size_t)(i - 1);
+    re = f[0] + dx * (f[1] + dx * (f[2] + dx * f[3])); /* cspevfn :239 */
+  } else { /* asymptotic expansion :408-414 (unreachable from damp_fund_ECH: |xi| <= 5) */
+    static const double A[6] = {1., 1. / 2., 3. / 4., 15. / 8., 105. / 16., 945. / 32.};
+    const double z_inv = 1.0 / z;
+    re = 0.;
+    for (int i = 1; i <= 6; i++) re = re - pow(z_inv, 2 * i - 1) * A[i - 1];
+  }
+  const double sqrt_pi = sqrt(3.14159265358979323846);
+  return c_make(re, sqrt_pi * exp(-(z * z)));
+}
+
+static cplx zfun0_real_arg(double z, double kz) { /* :351-372 */
+  if (kz > 0.) return zfun_real_arg_spline(z);
+  return c_neg(zfun_real_arg_spline(-z));
+}
+
+/* --------------------------------------------------------------------------------------------
+ * DAMP_FUND_ECH             damp_fund_ECH.f90:2-128
+ * D_WARM and DELTA are default COMPLEX (single precision, :36): both assignments truncate.
+ * ------------------------------------------------------------------------------------------ */
+static void damp_fund_ech(const rays_params_t* P, rf_ctx rf, const eq_point* eq, const double* v,
+                          const double vg[3], double* ki) {
+  *ki = 0.;
+  const double k0 = rf.k0;
+  double kvec[3] = {v[3], v[4], v[5]};
+  double nvec[3] = {kvec[0] / k0, kvec[1] / k0, kvec[2] / k0};
+  double k3 = 0.;
+  for (int i = 0; i < 3; i++) k3 += kvec[i] * eq->bunit[i];
+  double s = 0.;
+  for (int i = 0; i < 3; i++) s += sq(kvec[i] - k3 * eq->bunit[i]);
+  const double k1 = sqrt(s);
+  const double R3 = k3 / k0, R1 = k1 / k0;
+  const double R1S = sq(R1), R3S = sq(R3), RS = R1S + R3S;
+  const double B1 = eq->gamma[0], BETAE = sq(B1);
+  if (R3 == 0.) return;
+  const double vth = sqrt(2. * eq->ts[0] / P->ms[0]);
+  const double VT = vth / P->clight;
+  const double xi = (rf.omgrf + eq->omgc[0]) / (k3 * vth);
+  if (fabs(xi) > 5.) return; /* also true for NaN? no: NaN > 5 is false -> continues, as in Fortran */
+  const cplx zf = zfun0_real_arg(xi, k3);
+  const double Pa = eq->alpha[0];
+  const double Q = Pa / 2. / (1 - B1);
+  const double L1 = (1. - Q) * RS * R1S + (1. - Pa) * RS * R3S - (1. - Q) * (1. - Pa) * (RS + R3S) -
+                    (1 - 2. * Q) * R1S + (1 - 2 * Q) * (1 - Pa);
+  const double L2 = -(Pa / B1 * (RS * R1S - (1. - 2. * Q) * R1S)) +
+                    Pa * Pa / 4. / BETAE * R1S / R3S * (RS + R3S - 2. * (1. - 2. * Q));
+  const double L5 = Pa * (RS * R3S - (1. - Q) * (RS + R3S) + (1. - 2. * Q));
+  const double F = (1. - B1) * R3 * VT * (L1 + L2 + R1S / 2. / R3 / BETAE * VT * xi * L5);
+  const cplx zinv = c_div(c_make(1., 0.), zf);
+  const cplx par = c_make(xi + zinv.re, 0. + zinv.im);
+  const cplx dw8 = c_neg(c_mul(c_make(F, 0.), par));
+  const float dw_re = (float)dw8.re, dw_im = (float)dw8.im; /* D_WARM is COMPLEX(4) */
+  const double A = 1. - Pa - BETAE;
+  const double B = -((1. - Pa) * A + sq(1. - Pa) - BETAE) + (A + (1. - Pa) * (1. - BETAE)) * R3S;
+  const double DDNX2 = 2. * A * R1S + B;
+  const double DDNZ = 2. * R3 * ((A + (1. - Pa) * (1. - BETAE)) * R1S + (1 - Pa) * (2. * (1. - BETAE) * R3S - 2. * A));
+  double DDN[3], vgu[3];
+  const double nvg = sqrt((0. + sq(vg[0]) + sq(vg[1])) + sq(vg[2]));
+  double dot = 0.;
+  for (int i = 0; i < 3; i++) {
+    DDN[i] = DDNX2 * (2 * (nvec[i] - R3 * eq->bunit[i])) + DDNZ * eq->bunit[i];
+    vgu[i] = vg[i] / nvg;
+  }
+  for (int i = 0; i < 3; i++) dot += DDN[i] * vgu[i];
+  const cplx d8 = c_div(c_make(-(double)dw_re, -(double)dw_im), c_make(dot, 0.));
+  const float delta_im = (float)d8.im; /* DELTA is COMPLEX(4) */
+  *ki = k0 * (double)delta_im;          /* ksi(0) = k0*aimag(DELTA); ki = ksi(0) */
+}
+
+/* --------------------------------------------------------------------------------------------
  * eqn_ray                  eqn_ray.f90:1-236     returns stop code (0 = ok)
  * ------------------------------------------------------------------------------------------ */
 static int eqn_ray(const rays_params_t* P, rf_ctx rf, const double* v, double* dvds) {
@@ -676,6 +783,12 @@ static int eqn_ray(const rays_params_t* P, rf_ctx rf, const double* v, double* d
   }
   dvds[6] = dsd; /* :190 */
   int nv0 = 7;
+  if (P->damping_model != RAYS_DAMP_NONE) { /* :196-213 */
+    double ki;
+    damp_fund_ech(P, rf, &eq, v, vg, &ki);
+    dvds[7] = dsd * 2. * ki * (1. - v[7]);
+    nv0 = 8;
+  }
   if (P->integrate_eq_gradients) { /* :217-229 */
     for (int j = 0; j < 3; j++) {
       double a = 0.;
@@ -735,6 +848,12 @@ static int check_save(const rays_params_t* P, rf_ctx rf, const double* v, double
     *stop = 1;
     flag = RAYS_STOP_INFINITE_VG_CHECK; /* :107-108 */
   }
+  if (P->damping_model != RAYS_DAMP_NONE) { /* :114-125 (the damping() call only feeds messages) */
+    if (v[7] > P->total_damping_limit) {
+      *stop = 1;
+      flag = RAYS_STOP_TOTAL_ABSORPTION;
+    }
+  }
   return flag;
 }
 
@@ -777,19 +896,26 @@ static void initialize_ode_vector(const rays_params_t* P, rf_ctx rf, const doubl
   for (int i = 0; i < 3; i++) v[i] = r0[i];
   for (int i = 0; i < 3; i++) v[3 + i] = rf.k0 * n0[i];
   v[6] = 0.;
+  int nv0 = 7;
+  if (P->damping_model != RAYS_DAMP_NONE) {
+    v[7] = 0.;
+    nv0 = 8;
+  }
   if (P->integrate_eq_gradients) {
     eq_point eq;
     equilibrium(P, rf, v, &eq, 0);
-    for (int i = 0; i < 3; i++) v[7 + i] = eq.bvec[i];
-    v[10] = eq.ns[0];
-    v[11] = eq.ts[0];
+    for (int i = 0; i < 3; i++) v[nv0 + i] = eq.bvec[i];
+    v[nv0 + 3] = eq.ns[0];
+    v[nv0 + 4] = eq.ts[0];
   }
 }
 
 int rays_oracle_check_params(const rays_params_t* P) {
   if (P->abi_version != RAYS_ABI_VERSION) return 1;
   if (P->nspec < 0 || P->nspec > RAYS_NSPEC0) return 2;
-  if (P->nv != 7 + (P->integrate_eq_gradients ? 5 : 0)) return 3;
+  if (P->nv != 7 + (P->damping_model ? 1 : 0) + (P->integrate_eq_gradients ? 5 : 0)) return 3;
+  if (P->multi_spec_damping) return 5;
+  if (P->damping_model == RAYS_DAMP_FUND_ECH && !zf_fspl) return 6;
   if (P->nv > RAYS_ORACLE_NV_MAX) return 3;
   if (P->equilib_model == RAYS_EQ_SOLOVEV)
     for (int is = 0; is <= P->nspec; is++)

@@ -4,7 +4,7 @@
 #define RAYS_ORACLE_H
 #include "../include/rays_hip.h"
 
-#define RAYS_ORACLE_NV_MAX 12
+#define RAYS_ORACLE_NV_MAX 13
 
 #ifdef __cplusplus
 extern "C" {
@@ -13,6 +13,9 @@ extern "C" {
 typedef int (*rays_oracle_rhs_fn)(void* ctx, const double* v, double* dvds);
 
 int rays_oracle_check_params(const rays_params_t* P);
+
+/* Z-function spline table for damp_fund_ECH (same meaning as rays_hip_set_zfun_table). */
+int rays_oracle_set_zfun_table(const double* fspl_re, int nx, double x_min, double x_max);
 
 /* Same argument meaning as rays_hip_trace (include/rays_hip.h); host pointers; nthreads <= 0 =
  * all OpenMP threads.  nrhs_total (optional) counts eqn_ray calls made by the SG stepper. */

@@ -23,12 +23,13 @@ program ref_dump_driver
     use ray_results_m, only : ray_vec, residual, npoints, ray_stop_flag, end_ray_vec
     use equilibrium_m, only : equilibrium, eq_point, equilib_model
     use solovev_eq_m, only : rmaj, kappa, bphi0, iota0, outer_bound, psiB
+    use zfunctions_m, only : fsplRe, zf_nx => nx, x_grid_min, x_grid_max
     use omp_lib
     implicit none
 
     logical :: read_input = .true.
     character(len=256) :: fname, sval
-    integer :: u, stat, probe_stride, reps, irep, iray, j, nprobe, is
+    integer :: u, u2, stat, probe_stride, reps, irep, iray, j, nprobe, is
     real(kind=rkind) :: t0, t1, wall, resid, s
     real(kind=rkind), allocatable :: v(:), dvds(:)
     real(kind=rkind) :: dddx(3), dddk(3), dddw, ndx(3), ndk(3), ndw, nvec(3)
@@ -117,6 +118,15 @@ program ref_dump_driver
     write(u) ray_vec
     write(u) residual
     write(u) end_ray_vec
+
+    call get_environment_variable('RAYS_DUMP_ZFUN', sval, status=stat)
+    if (stat == 0 .and. len_trim(sval) > 0) then   ! Z-function spline table (zfunctions_m)
+       open(newunit=u2, file=trim(sval), access='stream', form='unformatted', status='replace')
+       write(u2) zf_nx
+       write(u2) x_grid_min, x_grid_max
+       write(u2) fsplRe
+       close(u2)
+    end if
 
     ! ---- optional per-state probes of the RHS pieces (unit parity for the restatement) ----
     if (probe_stride > 0) then

@@ -97,6 +97,38 @@ const rays::KernelEntry* find_kernel(const rays_params_t& p) {
   return nullptr;
 }
 
+// Z-function spline table (host copy + lazily uploaded per-device copies)
+struct ZfunTable {
+  std::vector<double> host;  // [nx][4]
+  int nx = 0;
+  double xmin = 0., xmax = 0.;
+  unsigned long long version = 0;
+};
+ZfunTable g_zfun;
+struct ZfunDevice {
+  double* ptr = nullptr;
+  unsigned long long version = 0;
+};
+std::vector<ZfunDevice> g_zfun_dev;
+
+int get_zfun_device(const double** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_zfun.nx <= 0) return fail("damping_model = 'damp_fund_ECH' needs rays_hip_set_zfun_table() first");
+  if ((int)g_zfun_dev.size() <= dev) g_zfun_dev.resize(dev + 1);
+  ZfunDevice& z = g_zfun_dev[dev];
+  if (z.version != g_zfun.version) {
+    if (z.ptr) (void)hipFree(z.ptr);
+    z.ptr = nullptr;
+    HIP_TRY(hipMalloc(&z.ptr, sizeof(double) * g_zfun.host.size()));
+    HIP_TRY(hipMemcpy(z.ptr, g_zfun.host.data(), sizeof(double) * g_zfun.host.size(), hipMemcpyHostToDevice));
+    z.version = g_zfun.version;
+  }
+  *out = z.ptr;
+  return 0;
+}
+
 // Per-device ring of refill counters (allocated once, outside any stream capture).
 struct DeviceWorkspace {
   unsigned int* counters = nullptr;
@@ -133,6 +165,17 @@ const char* rays_hip_stop_flag_text(int stop_code) {
   for (const FlagText& f : kFlags)
     if (f.code == stop_code) return f.text;
   return "";
+}
+
+int rays_hip_set_zfun_table(const double* fspl_re, int nx, double x_min, double x_max) {
+  if (!fspl_re || nx < 2 || !(x_max > x_min)) return fail("rays_hip_set_zfun_table: bad table");
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_zfun.host.assign(fspl_re, fspl_re + 4 * (size_t)nx);
+  g_zfun.nx = nx;
+  g_zfun.xmin = x_min;
+  g_zfun.xmax = x_max;
+  g_zfun.version++;
+  return 0;
 }
 
 int rays_hip_sizeof_params(void) { return (int)sizeof(rays_params_t); }
@@ -180,8 +223,11 @@ int rays_hip_check_params(const rays_params_t* p) {
     return fail("EQN_RAY: invalid ray parameter");  // eqn_ray.f90:183-185
   if (p->equilib_model != RAYS_EQ_SLAB && p->equilib_model != RAYS_EQ_SOLOVEV)
     return fail("equilibrium_m: invalid equilibrium model (device path: slab | solovev)");
-  if (p->nv != 7 + (p->integrate_eq_gradients ? 5 : 0))
-    return fail("rays_hip: nv must be 7 (+5 with integrate_eq_gradients); damping rows are not on the device path");
+  if (p->damping_model != RAYS_DAMP_NONE && p->damping_model != RAYS_DAMP_FUND_ECH)
+    return fail("damping: Unimplemented damping model");  // damping_m.f90:103-106
+  if (p->multi_spec_damping) return fail("rays_hip: multi_spec_damping is not on the device path");
+  if (p->nv != 7 + (p->damping_model ? 1 : 0) + (p->integrate_eq_gradients ? 5 : 0))
+    return fail("rays_hip: nv must be 7 (+1 with damping, +5 with integrate_eq_gradients) (ode_m.f90:160-173)");
   if (p->nstep_max < 0) return fail("rays_hip: nstep_max < 0");
   if (p->equilib_model == RAYS_EQ_SOLOVEV) {
     if (p->solovev.dens_prof_model != RAYS_SOLOVEV_N_CONSTANT && p->solovev.dens_prof_model != RAYS_SOLOVEV_N_PARABOLIC)
@@ -242,7 +288,17 @@ int rays_hip_trace_device(const rays_params_t* p, int nray, const double* d_rvec
   A.end_residuals = d_end_residuals;
   A.max_residuals = d_max_residuals;
   A.next_ray = counter;
-  const rays::DevParams D = make_dev_params(*p);
+  rays::DevParams D = make_dev_params(*p);
+  if (p->damping_model == RAYS_DAMP_FUND_ECH) {
+    const double* zf = nullptr;
+    rc = get_zfun_device(&zf);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    D.zf_fspl = zf;
+    D.zf_nx = g_zfun.nx;
+    D.zf_xmin = g_zfun.xmin;
+    D.zf_xmax = g_zfun.xmax;
+  }
   int grid = 0;
   hipError_t e = find_kernel(*p)->launch(D, A, stream, &grid);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");

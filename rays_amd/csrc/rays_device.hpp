@@ -31,6 +31,9 @@ namespace rays {
 // ---------------------------------------------------------------------------------------------
 struct DevParams {
   int nspec, nstep_max, ray_param, nv;
+  int damping_model, zf_nx;                 // damping_m.f90:30-40; Z-function spline grid size
+  double total_damping_limit, zf_xmin, zf_xmax;
+  const double* zf_fspl;                    // device pointer: fsplRe[nx][4] (zfunctions_m.f90)
   double ds, s_max, omgrf, k0, clight, eps0, resid_limit;
   double omgrf2;               // omgrf**2                      equilibrium_m.f90:264
   double two_over_k0;          // 2./k0                         deriv_cold.f90:51
@@ -139,7 +142,8 @@ struct EqPoint {
   double bvec[3], bmag, gradbmag[3], bunit[3], gradbunit[3][3], gbt[3][3];
   double ns[NS], gradns[NS][3], ts0, gradts0[3];
   double alpha[NS], gamma[NS];
-  Recip rbmag;  // shared reciprocal of |B|
+  double omgc0;  // electron cyclotron frequency (signed), for damp_fund_ECH
+  Recip rbmag;   // shared reciprocal of |B|
   int err;
 };
 
@@ -413,6 +417,7 @@ RAYS_DEV void equilibrium(const DevParams& P, const Recip& Romgrf, const Recip& 
     const double omgp2 = div(ns[is] * P.qs2[is], const_recip(P.eps0ms[is], P.inv_eps0ms[is]));
     eq.alpha[is] = div(omgp2, Romgrf2);
     eq.gamma[is] = div(omgc, Romgrf);
+    if (is == 0) eq.omgc0 = omgc;
   }
   eq.ts0 = ts[0];
 #pragma unroll
@@ -667,12 +672,127 @@ RAYS_DEV void deriv_num(const DevParams& P, const EqPoint<NS>& eq0, const double
 }
 
 // ---------------------------------------------------------------------------------------------
+// Damping: damp_fund_ECH (damp_fund_ECH.f90:2-128) with the splined Z function of a real argument
+// (zfunctions_m.f90:351-432; cspevx/cspevfn on the uniform grid, cspeval.f90:138-146,239).
+// D_WARM and DELTA are default COMPLEX (single precision) in the reference (:36): both
+// assignments truncate to float, reproduced here.  Complex quotients follow __divdc3.
+// ---------------------------------------------------------------------------------------------
+struct Cplx {
+  double re, im;
+};
+RAYS_DEV Cplx divdc3(Cplx x, Cplx y) {  // compiler-rt __divdc3, finite operands
+  double c = y.re, d = y.im;
+  const double m = fmax(fabs(c), fabs(d));
+  int k = 0;
+  if (m > 0.0 && m < __builtin_inf()) {
+    k = ilogb(m);
+    c = scalbn(c, -k);
+    d = scalbn(d, -k);
+  }
+  const double denom = c * c + d * d;
+  Cplx r;
+  r.re = scalbn((x.re * c + x.im * d) / denom, -k);
+  r.im = scalbn((x.im * c - x.re * d) / denom, -k);
+  return r;
+}
+
+RAYS_DEV double zf_x(const DevParams& P, int i) {  // x_grid(i), 1-based (zfunctions_m.f90:444)
+  return P.zf_xmin + (double)(i - 1) * (P.zf_xmax - P.zf_xmin) / (double)(P.zf_nx - 1);
+}
+
+RAYS_DEV Cplx zfun_real_arg_spline(const DevParams& P, double z) {
+  double re;
+  if (fabs(z) <= 10.0) {  // spline_range
+    const int nxm = P.zf_nx - 1;
+    const double x1 = zf_x(P, 1), xn = zf_x(P, P.zf_nx);
+    const double t = 1 + nxm * (z - x1) / (xn - x1);
+    int i = (int)t;  // NaN -> 0 on the device (undefined in Fortran); clamped below
+    i = i < nxm ? i : nxm;
+    i = i > 1 ? i : 1;
+    if (z < zf_x(P, i)) i = i - 1;
+    else if (z > zf_x(P, i + 1)) i = i + 1;
+    i = i < 1 ? 1 : (i > nxm ? nxm : i);
+    const double dx = z - zf_x(P, i);
+    const double* f = P.zf_fspl + 4 * (long long)(i - 1);
+    re = f[0] + dx * (f[1] + dx * (f[2] + dx * f[3]));
+  } else {  // asymptotic expansion :408-414 (unreachable from damp_fund_ECH: |xi| <= 5)
+    const double A[6] = {1., 1. / 2., 3. / 4., 15. / 8., 105. / 16., 945. / 32.};
+    const double z_inv = 1.0 / z;
+    re = 0.;
+    for (int i = 1; i <= 6; i++) re = re - pow(z_inv, (double)(2 * i - 1)) * A[i - 1];
+  }
+  Cplx r;
+  r.re = re;
+  r.im = 1.7724538509055159 * exp(-(z * z));  // sqrt(pi)
+  return r;
+}
+
+template <int NS>
+RAYS_DEV double damp_fund_ech(const DevParams& P, const EqPoint<NS>& eq, const double kvec[3],
+                              const double vg[3]) {
+  const double k0 = P.k0;
+  const Recip Rk0 = const_recip(P.k0, P.inv_k0);
+  const double nvec[3] = {div(kvec[0], Rk0), div(kvec[1], Rk0), div(kvec[2], Rk0)};
+  const double k3 = kvec[0] * eq.bunit[0] + kvec[1] * eq.bunit[1] + kvec[2] * eq.bunit[2];
+  const double k1 = sqrt(sq(kvec[0] - k3 * eq.bunit[0]) + sq(kvec[1] - k3 * eq.bunit[1]) +
+                         sq(kvec[2] - k3 * eq.bunit[2]));
+  const double R3 = div(k3, Rk0), R1 = div(k1, Rk0);
+  const double R1S = sq(R1), R3S = sq(R3), RS = R1S + R3S;
+  const double B1 = eq.gamma[0], BETAE = sq(B1);
+  if (R3 == 0.) return 0.;  // :59
+  const double vth = sqrt(2. * eq.ts0 / P.ms[0]);
+  const double VT = vth / P.clight;
+  const double xi = (P.omgrf + eq.omgc0) / (k3 * vth);
+  if (fabs(xi) > 5.) return 0.;  // :73
+  // zfun0_real_arg (:351-372).  The reference `stop 1`s the whole program when kz is neither
+  // > 0 nor < 0, i.e. when the state is already NaN (a ray that left a parabolic-density plasma);
+  // here the NaN simply propagates and the ray ends at check_save ('infinite_Vg') -- DESIGN.md.
+  Cplx zf;
+  if (k3 > 0.) {
+    zf = zfun_real_arg_spline(P, xi);
+  } else {
+    zf = zfun_real_arg_spline(P, -xi);
+    zf.re = -zf.re;
+    zf.im = -zf.im;
+  }
+  const double Pa = eq.alpha[0];
+  const double Q = Pa / 2. / (1 - B1);
+  const double L1 = (1. - Q) * RS * R1S + (1. - Pa) * RS * R3S - (1. - Q) * (1. - Pa) * (RS + R3S) -
+                    (1 - 2. * Q) * R1S + (1 - 2 * Q) * (1 - Pa);
+  const double L2 = -(Pa / B1 * (RS * R1S - (1. - 2. * Q) * R1S)) +
+                    Pa * Pa / 4. / BETAE * R1S / R3S * (RS + R3S - 2. * (1. - 2. * Q));
+  const double L5 = Pa * (RS * R3S - (1. - Q) * (RS + R3S) + (1. - 2. * Q));
+  const double F = (1. - B1) * R3 * VT * (L1 + L2 + R1S / 2. / R3 / BETAE * VT * xi * L5);
+  const Cplx one = {1., 0.};
+  const Cplx zinv = divdc3(one, zf);
+  const double par_re = xi + zinv.re, par_im = 0. + zinv.im;
+  // -(F,0)*(par): (F*a - 0*b, 0*a + F*b), negated, truncated to COMPLEX(4)
+  const float dw_re = (float)(-(F * par_re - 0. * par_im));
+  const float dw_im = (float)(-(0. * par_re + F * par_im));
+  const double A = 1. - Pa - BETAE;
+  const double B = -((1. - Pa) * A + sq(1. - Pa) - BETAE) + (A + (1. - Pa) * (1. - BETAE)) * R3S;
+  const double DDNX2 = 2. * A * R1S + B;
+  const double DDNZ = 2. * R3 * ((A + (1. - Pa) * (1. - BETAE)) * R1S + (1 - Pa) * (2. * (1. - BETAE) * R3S - 2. * A));
+  const double nvg = sqrt(sq(vg[0]) + sq(vg[1]) + sq(vg[2]));
+  double dot = 0.;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const double ddn = DDNX2 * (2 * (nvec[i] - R3 * eq.bunit[i])) + DDNZ * eq.bunit[i];
+    dot += ddn * (vg[i] / nvg);
+  }
+  const Cplx num = {-(double)dw_re, -(double)dw_im};
+  const Cplx den = {dot, 0.};
+  const float delta_im = (float)divdc3(num, den).im;  // DELTA is COMPLEX(4)
+  return k0 * (double)delta_im;                        // ksi(0) = k0*aimag(DELTA)
+}
+
+// ---------------------------------------------------------------------------------------------
 // eqn_ray tail               eqn_ray.f90:131-229: group velocity + ray equations from dD/d(x,k,w).
 // Returns a stop code (0 = ok).  NV = 7 (+5 with integrate_eq_gradients).
 // ---------------------------------------------------------------------------------------------
 template <int NS, int NV>
-RAYS_DEV int ray_equations(const DevParams& P, const EqPoint<NS>& eq, const double dddx[3],
-                           const double dddk[3], double dddw, double dvds[NV]) {
+RAYS_DEV int ray_equations(const DevParams& P, const EqPoint<NS>& eq, const double kvec[3], double v7,
+                           const double dddx[3], const double dddk[3], double dddw, double dvds[NV]) {
   if (!(dddw != 0.)) return RAYS_STOP_INFINITE_VG_RHS;  // :133 (`/= 0.` is true for NaN)
   const Recip Rw = make_recip(dddw);
   double vg[3];
@@ -702,16 +822,22 @@ RAYS_DEV int ray_equations(const DevParams& P, const EqPoint<NS>& eq, const doub
     dsd = vg0;
   }
   dvds[6] = dsd;  // :190
-  if (NV > 7) {   // :217-229 integrate_eq_gradients
+  constexpr bool DAMP = (NV == 8 || NV == 13);
+  constexpr int NV0 = DAMP ? 8 : 7;
+  if (DAMP) {  // :196-204
+    const double ki = damp_fund_ech<NS>(P, eq, kvec, vg);
+    dvds[7] = dsd * 2. * ki * (1. - v7);
+  }
+  if (NV >= 12) {  // :217-229 integrate_eq_gradients
     const Recip Rvg0 = make_recip(vg0);
     double vu[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) vu[i] = div(vg[i], Rvg0);
 #pragma unroll
     for (int j = 0; j < 3; j++)
-      dvds[7 + j] = dsd * vu[0] * eq.gbt[0][j] + dsd * vu[1] * eq.gbt[1][j] + dsd * vu[2] * eq.gbt[2][j];
-    dvds[10] = dsd * vu[0] * eq.gradns[0][0] + dsd * vu[1] * eq.gradns[0][1] + dsd * vu[2] * eq.gradns[0][2];
-    dvds[11] = dsd * vu[0] * eq.gradts0[0] + dsd * vu[1] * eq.gradts0[1] + dsd * vu[2] * eq.gradts0[2];
+      dvds[NV0 + j] = dsd * vu[0] * eq.gbt[0][j] + dsd * vu[1] * eq.gbt[1][j] + dsd * vu[2] * eq.gbt[2][j];
+    dvds[NV0 + 3] = dsd * vu[0] * eq.gradns[0][0] + dsd * vu[1] * eq.gradns[0][1] + dsd * vu[2] * eq.gradns[0][2];
+    dvds[NV0 + 4] = dsd * vu[0] * eq.gradts0[0] + dsd * vu[1] * eq.gradts0[1] + dsd * vu[2] * eq.gradts0[2];
   }
   return 0;
 }
@@ -731,7 +857,7 @@ RAYS_DEV int eqn_ray(const DevParams& P, const double v[NV], double dvds[NV]) {
   } else {
     deriv_num<EQ, NS>(P, eq, rvec, kvec, dddx, dddk, dddw);
   }
-  return ray_equations<NS, NV>(P, eq, dddx, dddk, dddw, dvds);
+  return ray_equations<NS, NV>(P, eq, kvec, v[NV > 7 ? 7 : 0], dddx, dddk, dddw, dvds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -789,8 +915,14 @@ RAYS_DEV void rhs_eval(const DevParams& P, const double v[NV], bool do_check, do
       cs_flag = RAYS_STOP_INFINITE_VG_CHECK;  // :107-108
     }
   }
+  if (do_check && (NV == 8 || NV == 13)) {  // check_save.f90:114-125
+    if (v[NV > 7 ? 7 : 0] > P.total_damping_limit) {
+      cs_stop = true;
+      cs_flag = RAYS_STOP_TOTAL_ABSORPTION;
+    }
+  }
   if (DERIV == RAYS_DERIV_NUM) deriv_num<EQ, NS>(P, eq, rvec, kvec, dddx, dddk, dddw);
-  const int rc = ray_equations<NS, NV>(P, eq, dddx, dddk, dddw, f);
+  const int rc = ray_equations<NS, NV>(P, eq, kvec, v[NV > 7 ? 7 : 0], dddx, dddk, dddw, f);
   code = eq.err ? eq.err : rc;  // eqn_ray.f90:90-102 returns before the derivatives
 }
 
@@ -804,15 +936,18 @@ RAYS_DEV void initialize_ode_vector(const DevParams& P, const double* __restrict
     v[3 + i] = P.k0 * n0[i];
   }
   v[6] = 0.;
-  if (NV > 7) {
+  constexpr bool DAMP = (NV == 8 || NV == 13);
+  constexpr int NV0 = DAMP ? 8 : 7;
+  if (DAMP) v[7] = 0.;
+  if (NV >= 12) {
     EqPoint<NS> eq;
     const double rvec[3] = {v[0], v[1], v[2]};
     equilibrium<EQ, NS>(P, const_recip(P.omgrf, P.inv_omgrf), const_recip(P.omgrf2, P.inv_omgrf2), rvec, eq, false);
-    v[7] = eq.bvec[0];
-    v[8] = eq.bvec[1];
-    v[9] = eq.bvec[2];
-    v[10] = eq.ns[0];
-    v[11] = eq.ts0;
+    v[NV0] = eq.bvec[0];
+    v[NV0 + 1] = eq.bvec[1];
+    v[NV0 + 2] = eq.bvec[2];
+    v[NV0 + 3] = eq.ns[0];
+    v[NV0 + 4] = eq.ts0;
   }
 }
 

@@ -1,7 +1,7 @@
 // rays_inst.hip -- kernel instantiations.  Compiled once per (solver, equilibrium, derivative)
 // group:  -DRAYS_INST_SOLVER={0,1} -DRAYS_INST_EQ={0,1} -DRAYS_INST_DERIV={0,1}
 // Each group instantiates the species counts NS = 1..6 (nspec = 0..5, species_m.f90:25) and
-// nv = 7 | 12 (integrate_eq_gradients, ode_m.f90:160-173).
+// nv = 7 | 12 (integrate_eq_gradients) and 8 | 13 (+ damping) (ode_m.f90:160-173).
 #include "rays_launch.hpp"
 #if RAYS_INST_SOLVER == 0
 #include "rays_rk4.hpp"
@@ -41,6 +41,9 @@ hipError_t launch_one(const DevParams& P, const TraceArgs& A, hipStream_t stream
 const KernelEntry kEntries[] = {
     RAYS_ENTRY(1, 7), RAYS_ENTRY(2, 7), RAYS_ENTRY(3, 7), RAYS_ENTRY(4, 7), RAYS_ENTRY(5, 7), RAYS_ENTRY(6, 7),
     RAYS_ENTRY(1, 12), RAYS_ENTRY(2, 12), RAYS_ENTRY(3, 12), RAYS_ENTRY(4, 12), RAYS_ENTRY(5, 12), RAYS_ENTRY(6, 12),
+    // nv = 8 | 13: + total-absorption row (damping_model = 'damp_fund_ECH', ode_m.f90:162-166)
+    RAYS_ENTRY(1, 8), RAYS_ENTRY(2, 8), RAYS_ENTRY(3, 8), RAYS_ENTRY(4, 8), RAYS_ENTRY(5, 8), RAYS_ENTRY(6, 8),
+    RAYS_ENTRY(1, 13), RAYS_ENTRY(2, 13), RAYS_ENTRY(3, 13), RAYS_ENTRY(4, 13), RAYS_ENTRY(5, 13), RAYS_ENTRY(6, 13),
 };
 }  // namespace
 

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "librays_hip.so")
 # every symbol include/rays_hip.h declares
 EXPORTED_SYMBOLS = (
     "rays_hip_init", "rays_hip_finalize", "rays_hip_device_count", "rays_hip_sizeof_params",
-    "rays_hip_last_error",
+    "rays_hip_last_error", "rays_hip_set_zfun_table",
     "rays_hip_stop_flag_text", "rays_hip_check_params", "rays_hip_trace", "rays_hip_trace_device",
     "rays_hip_kernel_name", "rays_hip_probe", "rays_hip_pack_device", "rays_hip_unpack_device",
 )
@@ -53,6 +53,8 @@ def load():
     lib.rays_hip_last_error.argtypes = [C.c_char_p, C.c_int]
     lib.rays_hip_stop_flag_text.restype = C.c_char_p
     lib.rays_hip_stop_flag_text.argtypes = [C.c_int]
+    lib.rays_hip_set_zfun_table.restype = C.c_int
+    lib.rays_hip_set_zfun_table.argtypes = [dp, C.c_int, C.c_double, C.c_double]
     lib.rays_hip_check_params.restype = C.c_int
     lib.rays_hip_check_params.argtypes = [pp]
     lib.rays_hip_kernel_name.restype = C.c_char_p
@@ -86,6 +88,28 @@ def stop_flag_text(code: int) -> str:
     return load().rays_hip_stop_flag_text(int(code)).decode()
 
 
+_ZFUN_PATH = os.path.join(_HERE, "data", "zfun_spline_re.npz")
+_zfun_set = False
+
+
+def set_zfun_table(fspl_re=None, x_min=None, x_max=None):
+    """Hand the Z-function spline table (fsplRe[nx][4]) to the library.  Default: the table shipped
+    in rays_amd/data (cut from the reference's initialize_spline_coeffs, zfunctions_m.f90:436-466)."""
+    global _zfun_set
+    if fspl_re is None:
+        z = np.load(_ZFUN_PATH)
+        fspl_re, x_min, x_max = z["fspl_re"], float(z["x_min"]), float(z["x_max"])
+    fspl_re = np.ascontiguousarray(fspl_re, dtype=np.float64)
+    _check(load().rays_hip_set_zfun_table(_dp(fspl_re), len(fspl_re), float(x_min), float(x_max)),
+           "rays_hip_set_zfun_table")
+    _zfun_set = True
+
+
+def ensure_tables(p: RaysParams):
+    if p.damping_model and not _zfun_set:
+        set_zfun_table()
+
+
 def check_params(p: RaysParams):
     _check(load().rays_hip_check_params(C.byref(p)), "rays_hip_check_params")
 
@@ -110,6 +134,7 @@ def trace_host(p: RaysParams, rvec0, rindex_vec0, ngpu: int = 0) -> dict:
     nray, nv, npt = len(rvec0), p.nv, p.nstep_max + 1
     if lib.rays_hip_init(int(ngpu)) < 0:
         raise RaysHipError("rays_hip_init: " + last_error())
+    ensure_tables(p)
     out = dict(
         ray_vec=np.zeros((nray, npt, nv)), residual=np.zeros((nray, npt)),
         npoints=np.zeros(nray, dtype=np.int32), stop_code=np.zeros(nray, dtype=np.int32),
@@ -129,6 +154,7 @@ def trace_device(p: RaysParams, nray: int, d_rvec0: int, d_rindex_vec0: int, d_r
                  d_end_residuals: int = 0, d_max_residuals: int = 0, stream: int = 0,
                  zero_fill: bool = True):
     """rays_hip_trace_device: raw device pointers (ints), asynchronous on `stream`."""
+    ensure_tables(p)
     rc = load().rays_hip_trace_device(
         C.byref(p), int(nray), d_rvec0, d_rindex_vec0, d_ray_vec, d_residual, d_npoints, d_stop_code,
         d_end_ray_vec or None, d_end_residuals or None, d_max_residuals or None, stream or None,

@@ -15,7 +15,7 @@ from typing import Any, Dict
 import numpy as np
 
 NS0 = 6  # species_m.f90:25 nspec0 = 5 -> arrays 0:5
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ODE = {"RK4_ODE": 0, "SG_ODE": 1}
 DERIV = {"cold": 0, "numerical": 1}
@@ -28,6 +28,7 @@ SLAB_N = {"constant": 0, "linear": 1, "linear_2": 2, "parabolic": 3, "Gaussian":
 SLAB_T = {"zero": 0, "constant": 1, "linear": 2, "linear_2": 3, "parabolic": 4}
 SOLOVEV_N = {"constant": 0, "parabolic": 1}
 SOLOVEV_T = {"zero": 0, "parabolic": 2}
+DAMPING = {"no_damp": 0, "damp_fund_ECH": 1}
 
 # per-ray stop codes <-> reference ode_stop_flag strings (include/rays_hip.h)
 STOP_FLAG_TEXT = {
@@ -101,6 +102,8 @@ class RaysParams(C.Structure):
         ("qs", C.c_double * NS0), ("ms", C.c_double * NS0),
         ("n0s", C.c_double * NS0), ("t0s", C.c_double * NS0), ("eta", C.c_double * NS0),
         ("slab", SlabParams), ("solovev", SolovevParams),
+        ("damping_model", C.c_int32), ("multi_spec_damping", C.c_int32),
+        ("total_damping_limit", C.c_double),
     ]
 
 
@@ -207,11 +210,12 @@ def params_from_namelist(nml: Dict[str, Dict[str, Any]]) -> RaysParams:
     p.ray_param = _lookup(RAY_PARAM, rf.get("ray_param", "arcl"), "ray parameter")
     p.dispersion_resid_limit = float(rf.get("dispersion_resid_limit", 0.0))
 
-    # ---- damping_m: only 'no_damp' is on the round-1 device path ---------------------------
-    if str(damp.get("damping_model", "no_damp")).strip() != "no_damp":
-        raise ConfigError("damping_model /= 'no_damp' is not on the device path yet (SURVEY a17)")
-    if bool(damp.get("multi_spec_damping", False)):
+    # ---- damping_m.f90:46-68 ---------------------------------------------------------------
+    p.damping_model = _lookup(DAMPING, damp.get("damping_model", "no_damp"), "damping model")
+    p.multi_spec_damping = 1 if bool(damp.get("multi_spec_damping", False)) else 0
+    if p.multi_spec_damping:
         raise ConfigError("multi_spec_damping is not on the device path yet")
+    p.total_damping_limit = float(damp.get("total_damping_limit", _f32(0.99)))
 
     # ---- equilibrium ---------------------------------------------------------------------
     p.equilib_model = _lookup(EQUILIB, eql.get("equilib_model", ""), "equilibrium model")
@@ -259,7 +263,7 @@ def params_from_namelist(nml: Dict[str, Dict[str, Any]]) -> RaysParams:
     p.s_max = float(ode.get("s_max", 0.0))
     p.ds = float(ode.get("ds", 0.0))
     p.integrate_eq_gradients = 1 if bool(diag.get("integrate_eq_gradients", False)) else 0
-    p.nv = 7 + (5 if p.integrate_eq_gradients else 0)
+    p.nv = 7 + (1 if p.damping_model else 0) + (5 if p.integrate_eq_gradients else 0)  # ode_m.f90:160-173
     p.rel_err0 = float(sg.get("rel_err0", 0.0))
     p.abs_err0 = float(sg.get("abs_err0", 0.0))
     p.SG_error_limit = float(sg.get("sg_error_limit", _f32(0.1)))

@@ -29,6 +29,14 @@ def build(sanitize: bool = False):
     subprocess.check_call(cmd)
 
 
+def _set_zfun(fn):
+    """Z-function spline table for damp_fund_ECH: the data file cut from the reference's
+    initialize_spline_coeffs (rays_amd/data/zfun_spline_re.npz)."""
+    z = np.load(os.path.join(_ROOT, "rays_amd", "data", "zfun_spline_re.npz"))
+    f = np.ascontiguousarray(z["fspl_re"], dtype=np.float64)
+    fn(f.ctypes.data_as(C.POINTER(C.c_double)), len(f), float(z["x_min"]), float(z["x_max"]))
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -37,6 +45,9 @@ def lib():
         dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
         _lib.rays_emul_trace.restype = C.c_int
         _lib.rays_emul_trace.argtypes = [C.POINTER(RaysParams), C.c_int, dp, dp, dp, dp, ip, ip, dp, dp, dp]
+        _lib.rays_emul_set_zfun_table.restype = C.c_int
+        _lib.rays_emul_set_zfun_table.argtypes = [dp, C.c_int, C.c_double, C.c_double]
+        _set_zfun(_lib.rays_emul_set_zfun_table)
     return _lib
 
 

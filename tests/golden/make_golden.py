@@ -30,6 +30,9 @@ CASES = [
     ("gold_solovev64_sg_cold", "gold_solovev64_sg_cold.in", list(range(0, 64, 5)), 0, 0),
     ("gold_solovev64_sg_num", "gold_solovev64_sg_num.in", list(range(0, 64, 5)), 0, 0),
     ("gold_solovev64_rk4_num", "gold_solovev64_rk4_num.in", list(range(0, 64, 5)), 0, 0),
+    # fundamental-ECH damping (damp_fund_ECH, nv = 8): constant density + parabolic Te, B0 = 3.3 T
+    ("gold_solovev64_damp_rk4", "gold_solovev64_damp_rk4.in", list(range(0, 64, 5)), 0, 0),
+    ("gold_solovev64_damp_sg", "gold_solovev64_damp_sg.in", list(range(0, 64, 5)), 0, 0),
 ]
 
 

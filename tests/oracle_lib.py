@@ -18,6 +18,14 @@ def build():
     subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), "librays_oracle.so"])
 
 
+def _set_zfun(fn):
+    """Z-function spline table for damp_fund_ECH: the data file cut from the reference's
+    initialize_spline_coeffs (rays_amd/data/zfun_spline_re.npz)."""
+    z = np.load(os.path.join(_ROOT, "rays_amd", "data", "zfun_spline_re.npz"))
+    f = np.ascontiguousarray(z["fspl_re"], dtype=np.float64)
+    fn(f.ctypes.data_as(C.POINTER(C.c_double)), len(f), float(z["x_min"]), float(z["x_max"]))
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -30,6 +38,9 @@ def lib():
                                            dp, dp, dp, C.c_int, C.POINTER(C.c_longlong)]
         _lib.rays_oracle_probe.restype = None
         _lib.rays_oracle_probe.argtypes = [C.POINTER(RaysParams), dp, dp, dp, dp, dp, dp, ip]
+        _lib.rays_oracle_set_zfun_table.restype = C.c_int
+        _lib.rays_oracle_set_zfun_table.argtypes = [dp, C.c_int, C.c_double, C.c_double]
+        _set_zfun(_lib.rays_oracle_set_zfun_table)
         _lib.rays_oracle_check_params.restype = C.c_int
         _lib.rays_oracle_check_params.argtypes = [C.POINTER(RaysParams)]
     return _lib

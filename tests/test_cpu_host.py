@@ -64,7 +64,7 @@ def test_config_errors():
     with pytest.raises(ConfigError):
         params_from_namelist(bad)
     bad = copy.deepcopy(nml)
-    bad["damping_list"]["damping_model"] = "damp_fund_ECH"
+    bad["damping_list"]["damping_model"] = "damp_landau"   # damping_m.f90:103-106 `stop 1`
     with pytest.raises(ConfigError):
         params_from_namelist(bad)
 
@@ -92,7 +92,7 @@ def test_c_abi_host_side_without_compute():
     g, nml, p = load_golden("cfg1_slab16_rk4")
     from rays_amd.params import copy_params
     q = copy_params(p)
-    q.nv = 8
+    q.nv = 9
     with pytest.raises(hip.RaysHipError):
         hip.check_params(q)
     q = copy_params(p)

@@ -30,7 +30,8 @@ def _run(binary, cfg, d):
 @pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(HIPBIN)),
                     reason="reference binaries not built (oracle/build_ref.sh needs /root/reference)")
 @pytest.mark.parametrize("cfg", ["cfg1_slab16_rk4.in", "cfg2_solovev1024_rk4.in",
-                                 "gold_solovev64_sg_cold.in", "gold_solovev64_rk4_num.in"])
+                                 "gold_solovev64_sg_cold.in", "gold_solovev64_rk4_num.in",
+                                 "gold_solovev64_damp_rk4.in"])
 def test_fortran_dropin_equals_reference_binary(cfg):
     with tempfile.TemporaryDirectory() as d:
         ref = _run(REF, cfg, os.path.join(d, "ref"))
@@ -39,6 +40,8 @@ def test_fortran_dropin_equals_reference_binary(cfg):
     np.testing.assert_array_equal(hipr["rvec0"], ref["rvec0"])
     np.testing.assert_array_equal(hipr["npoints"], ref["npoints"])
     assert hipr["stop_flag"] == ref["stop_flag"]          # the exact strings, leading blank included
-    np.testing.assert_array_equal(hipr["ray_vec"], ref["ray_vec"])      # bit-identical trajectories
+    np.testing.assert_array_equal(hipr["ray_vec"][..., :7], ref["ray_vec"][..., :7])  # bit-identical trajectories
+    if ref["nv"] > 7:  # absorbed power: single-precision temporaries in the reference + libm exp
+        np.testing.assert_allclose(hipr["ray_vec"][..., 7:], ref["ray_vec"][..., 7:], rtol=1e-6, atol=1e-9)
     np.testing.assert_array_equal(hipr["residual"], ref["residual"])
     np.testing.assert_array_equal(hipr["end_ray_vec"], ref["end_ray_vec"])
