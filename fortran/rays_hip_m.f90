@@ -11,14 +11,14 @@
     use, intrinsic :: iso_c_binding
     implicit none
 
-    integer(c_int), parameter :: RAYS_ABI_VERSION = 2
+    integer(c_int), parameter :: RAYS_ABI_VERSION = 3
     integer, parameter :: RAYS_NS0 = 6   ! species_m nspec0 + 1
 
     ! selectors
     integer(c_int32_t), parameter :: RAYS_ODE_RK4 = 0, RAYS_ODE_SG = 1
     integer(c_int32_t), parameter :: RAYS_DERIV_COLD = 0, RAYS_DERIV_NUM = 1
     integer(c_int32_t), parameter :: RAYS_PARAM_ARCL = 0, RAYS_PARAM_TIME = 1
-    integer(c_int32_t), parameter :: RAYS_EQ_SLAB = 0, RAYS_EQ_SOLOVEV = 1
+    integer(c_int32_t), parameter :: RAYS_EQ_SLAB = 0, RAYS_EQ_SOLOVEV = 1, RAYS_EQ_AXISYM = 2
     integer(c_int32_t), parameter :: RAYS_DAMP_NONE = 0, RAYS_DAMP_FUND_ECH = 1
 
     type, bind(C) :: rays_slab_params_t
@@ -44,6 +44,26 @@
         real(c_double) :: box_rmin, box_rmax, box_zmin, box_zmax
     end type rays_solovev_params_t
 
+    type, bind(C) :: rays_axisym_params_t
+        integer(c_int32_t) :: magnetics_model, density_prof_model
+        integer(c_int32_t) :: t_prof_model(RAYS_NS0)
+        real(c_double) :: box_rmin, box_rmax, box_zmin, box_zmax
+        real(c_double) :: plasma_psi_limit
+        real(c_double) :: psiB
+        real(c_double) :: alphan1, alphan2, d_scrape_off, T_scrape_off
+        real(c_double) :: alphat1(RAYS_NS0), alphat2(RAYS_NS0)
+    end type rays_axisym_params_t
+
+    ! spline tables of the eqdsk equilibrium: pointers to the host's own (contiguous) arrays
+    type, bind(C) :: rays_axisym_tables_t
+        integer(c_int32_t) :: nr, nz, n_rb, n_ne, n_te, n_ti
+        type(c_ptr) :: r_grid, z_grid, psi_fspl
+        type(c_ptr) :: rb_grid, rb_fspl
+        type(c_ptr) :: ne_grid, ne_fspl
+        type(c_ptr) :: te_grid, te_fspl
+        type(c_ptr) :: ti_grid, ti_fspl
+    end type rays_axisym_tables_t
+
     type, bind(C) :: rays_params_t
         integer(c_int32_t) :: abi_version
         integer(c_int32_t) :: nv, nspec, nstep_max
@@ -62,6 +82,7 @@
         type(rays_solovev_params_t) :: solovev
         integer(c_int32_t) :: damping_model, multi_spec_damping
         real(c_double) :: total_damping_limit
+        type(rays_axisym_params_t) :: axisym
     end type rays_params_t
 
     interface
@@ -93,6 +114,11 @@
           integer(c_int), value :: nx
           real(c_double), value :: x_min, x_max
        end function rays_hip_set_zfun_table
+
+       integer(c_int) function rays_hip_set_axisym_tables(t) bind(C, name='rays_hip_set_axisym_tables')
+          import :: c_int, rays_axisym_tables_t
+          type(rays_axisym_tables_t), intent(in) :: t
+       end function rays_hip_set_axisym_tables
 
        integer(c_int) function rays_hip_check_params(p) bind(C, name='rays_hip_check_params')
           import :: c_int, rays_params_t

@@ -28,6 +28,14 @@
          & v_dens => dens_prof_model, v_alphan1 => alphan1, v_alphan2 => alphan2, &
          & v_tmodel => t_prof_model, v_alphat1 => alphat1, v_alphat2 => alphat2, &
          & box_rmin, box_rmax, box_zmin, box_zmax
+    use axisym_toroid_eq_m, only : magnetics_model, a_dens => density_prof_model, a_tmodel => temperature_prof_model, &
+         & a_rmin => box_rmin, a_rmax => box_rmax, a_zmin => box_zmin, a_zmax => box_zmax, plasma_psi_limit, &
+         & a_alphan1 => alphan1, a_alphan2 => alphan2, d_scrape_off, T_scrape_off, &
+         & a_alphat1 => alphat1, a_alphat2 => alphat2
+    use eqdsk_magnetics_spline_interp_m, only : Psi_profile, T_profile
+    use eqdsk_utilities_m, only : PSIBOUND
+    use density_spline_interp_m, only : ne_profile_N
+    use temperature_spline_interp_m, only : Te_profileN, Ti_profileN
     use ode_m, only : nv, ds, s_max, nstep_max, ode_solver_name, ray_deriv_name
     use ray_init_m, only : nray, rvec0, rindex_vec0, ray_pwr_wt
     use ray_results_m, only : ray_stop_flag, ray_vec, residual, npoints, end_residuals, &
@@ -38,6 +46,10 @@
     implicit none
 
     type(rays_params_t) :: p
+    type(rays_axisym_tables_t) :: tab
+    ! contiguous TARGET copies of the host's spline objects (c_loc needs a target)
+    real(c_double), allocatable, target :: t_rg(:), t_zg(:), t_psi(:,:,:,:), t_rbg(:), t_rb(:,:)
+    real(c_double), allocatable, target :: t_neg(:), t_ne(:,:), t_teg(:), t_te(:,:), t_tig(:), t_ti(:,:)
     integer(c_int32_t), allocatable :: stop_code(:)
     integer(c_int) :: rc
     real(c_double) :: elapsed
@@ -150,6 +162,48 @@
        p%solovev%alphan1 = v_alphan1 ; p%solovev%alphan2 = v_alphan2
        p%solovev%box_rmin = box_rmin ; p%solovev%box_rmax = box_rmax
        p%solovev%box_zmin = box_zmin ; p%solovev%box_zmax = box_zmax
+    case ('axisym_toroid')
+       p%equilib_model = RAYS_EQ_AXISYM
+       p%axisym%magnetics_model = pick(magnetics_model, [character(len=32) :: 'eqdsk_magnetics_spline_interp'])
+       p%axisym%density_prof_model = pick(a_dens, [character(len=32) :: 'constant', 'parabolic', 'density_spline_interp'])
+       p%axisym%t_prof_model = 0 ; p%axisym%alphat1 = 0. ; p%axisym%alphat2 = 0.
+       do is = 0, nspec
+          p%axisym%t_prof_model(is+1) = pick(a_tmodel(is), [character(len=32) :: 'zero', 'constant', 'parabolic', &
+               & 'temperature_spline_interp'])
+          p%axisym%alphat1(is+1) = a_alphat1(is) ; p%axisym%alphat2(is+1) = a_alphat2(is)
+       end do
+       p%axisym%box_rmin = a_rmin ; p%axisym%box_rmax = a_rmax
+       p%axisym%box_zmin = a_zmin ; p%axisym%box_zmax = a_zmax
+       p%axisym%plasma_psi_limit = plasma_psi_limit
+       p%axisym%psiB = PSIBOUND     ! already PSIBOUND - PSIAXIS (eqdsk_magnetics_spline_interp_m.f90:172)
+       p%axisym%alphan1 = a_alphan1 ; p%axisym%alphan2 = a_alphan2
+       p%axisym%d_scrape_off = d_scrape_off ; p%axisym%T_scrape_off = T_scrape_off
+       ! spline tables built by initialize_eqdsk_magnetics_spline_interp / initialize_*_spline_interp
+       t_rg = Psi_profile%x_grid ; t_zg = Psi_profile%y_grid ; t_psi = Psi_profile%fspl
+       t_rbg = T_profile%x_grid ; t_rb = T_profile%fspl
+       tab%nr = Psi_profile%nx ; tab%nz = Psi_profile%ny ; tab%n_rb = T_profile%nx
+       tab%r_grid = c_loc(t_rg) ; tab%z_grid = c_loc(t_zg) ; tab%psi_fspl = c_loc(t_psi)
+       tab%rb_grid = c_loc(t_rbg) ; tab%rb_fspl = c_loc(t_rb)
+       tab%n_ne = 0 ; tab%n_te = 0 ; tab%n_ti = 0
+       tab%ne_grid = c_null_ptr ; tab%ne_fspl = c_null_ptr
+       tab%te_grid = c_null_ptr ; tab%te_fspl = c_null_ptr
+       tab%ti_grid = c_null_ptr ; tab%ti_fspl = c_null_ptr
+       if (allocated(ne_profile_N%fspl)) then
+          t_neg = ne_profile_N%x_grid ; t_ne = ne_profile_N%fspl
+          tab%n_ne = ne_profile_N%nx ; tab%ne_grid = c_loc(t_neg) ; tab%ne_fspl = c_loc(t_ne)
+       end if
+       if (allocated(Te_profileN%fspl)) then
+          t_teg = Te_profileN%x_grid ; t_te = Te_profileN%fspl
+          tab%n_te = Te_profileN%nx ; tab%te_grid = c_loc(t_teg) ; tab%te_fspl = c_loc(t_te)
+       end if
+       if (allocated(Ti_profileN%fspl)) then
+          t_tig = Ti_profileN%x_grid ; t_ti = Ti_profileN%fspl
+          tab%n_ti = Ti_profileN%nx ; tab%ti_grid = c_loc(t_tig) ; tab%ti_fspl = c_loc(t_ti)
+       end if
+       if (rays_hip_set_axisym_tables(tab) /= 0) then
+          call last_error_string(msg)
+          write(0,*) 'trace_rays (HIP): ', trim(msg) ; stop 1
+       end if
     case default
        write(0,*) 'trace_rays (HIP): equilib_model not on the device path = ', trim(equilib_model); stop 1
     end select
@@ -190,7 +244,7 @@
     integer(c_int32_t) function pick(name, table)
     ! index (0-based) of trim(name) in table; -1 if absent (rays_hip_check_params then rejects it)
        character(len=*), intent(in) :: name
-       character(len=12), intent(in) :: table(:)
+       character(len=*), intent(in) :: table(:)
        integer :: i
        pick = -1
        do i = 1, size(table)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define RAYS_ABI_VERSION 2
+#define RAYS_ABI_VERSION 3
 #define RAYS_NSPEC0 5 /* species_m.f90:25  nspec0; arrays are dimensioned 0:nspec0 */
 #define RAYS_NS0 (RAYS_NSPEC0 + 1)
 
@@ -43,7 +43,7 @@ extern "C" {
 enum { RAYS_ODE_RK4 = 0, RAYS_ODE_SG = 1 };           /* ode_m.f90:238  'RK4_ODE' | 'SG_ODE'   */
 enum { RAYS_DERIV_COLD = 0, RAYS_DERIV_NUM = 1 };     /* eqn_ray.f90:106 'cold' | 'numerical'  */
 enum { RAYS_PARAM_ARCL = 0, RAYS_PARAM_TIME = 1 };    /* eqn_ray.f90:148 'arcl' | 'time'       */
-enum { RAYS_EQ_SLAB = 0, RAYS_EQ_SOLOVEV = 1 };       /* equilibrium_m.f90:177                 */
+enum { RAYS_EQ_SLAB = 0, RAYS_EQ_SOLOVEV = 1, RAYS_EQ_AXISYM = 2 }; /* equilibrium_m.f90:177-189 */
 enum { RAYS_DAMP_NONE = 0, RAYS_DAMP_FUND_ECH = 1 };  /* damping_m.f90:94-101 'no_damp' | 'damp_fund_ECH' */
 
 /* slab_eq_m.f90:172-300 profile-model strings */
@@ -58,6 +58,11 @@ enum { RAYS_SLAB_T_ZERO = 0, RAYS_SLAB_T_CONSTANT, RAYS_SLAB_T_LINEAR, RAYS_SLAB
 enum { RAYS_SOLOVEV_N_CONSTANT = 0, RAYS_SOLOVEV_N_PARABOLIC };
 enum { RAYS_SOLOVEV_T_ZERO = 0, RAYS_SOLOVEV_T_PARABOLIC = 2 };
 
+/* axisym_toroid_eq_m.f90:56-100: magnetics / profile model strings */
+enum { RAYS_AXI_MAG_EQDSK_SPLINE = 0 }; /* 'eqdsk_magnetics_spline_interp' (the only one on the device) */
+enum { RAYS_AXI_N_CONSTANT = 0, RAYS_AXI_N_PARABOLIC, RAYS_AXI_N_SPLINE };
+enum { RAYS_AXI_T_ZERO = 0, RAYS_AXI_T_CONSTANT, RAYS_AXI_T_PARABOLIC, RAYS_AXI_T_SPLINE };
+
 /* ---- per-ray stop codes  <->  reference ode_stop_flag strings ---------------------------- */
 enum {
   RAYS_STOP_NONE = 0,
@@ -70,6 +75,9 @@ enum {
   RAYS_STOP_NEGATIVE_TEMP = 14,    /* 'negative_temp'           slab_eq_m.f90:306, solovev_eq_m.f90:273 */
   RAYS_STOP_R_OUT_OF_BOX = 20,     /* 'R out_of_box'            solovev_eq_m.f90:155 */
   RAYS_STOP_Z_OUT_OF_BOX = 21,     /* 'z out_of_box'            solovev_eq_m.f90:156 */
+  RAYS_STOP_AXI_R_OUT_OF_BOX = 22, /* 'R_out_of_box'            axisym_toroid_eq_m.f90:263 */
+  RAYS_STOP_AXI_Z_OUT_OF_BOX = 23, /* 'Z_out_of_box'            axisym_toroid_eq_m.f90:267 */
+  RAYS_STOP_OUT_OF_PLASMA = 24,    /* 'out_of_plasma'           axisym_toroid_eq_m.f90:288 */
   RAYS_STOP_INFINITE_VG_RHS = 30,  /* 'infinite Vg'             eqn_ray.f90:142 */
   RAYS_STOP_RAY_STALLED = 31,      /* 'ray stalled'             eqn_ray.f90:168 */
   RAYS_STOP_DISP_RESIDUAL = 40,    /* 'dispersion_residual'     check_save.f90:70 */
@@ -108,6 +116,17 @@ typedef struct rays_solovev_params {
   double box_rmin, box_rmax, box_zmin, box_zmax;
 } rays_solovev_params_t;
 
+/* ---- axisym_toroid_eq_m.f90:56-100 namelist /axisym_toroid_eq_list/ + eqdsk-derived scalars ---- */
+typedef struct rays_axisym_params {
+  int32_t magnetics_model, density_prof_model;
+  int32_t t_prof_model[RAYS_NS0];
+  double box_rmin, box_rmax, box_zmin, box_zmax; /* from the eqdsk (eqdsk_magnetics_spline_interp_m.f90:115-118) */
+  double plasma_psi_limit;
+  double psiB; /* PSIBOUND - PSIAXIS (eqdsk_magnetics_spline_interp_m.f90:171-173) */
+  double alphan1, alphan2, d_scrape_off, T_scrape_off;
+  double alphat1[RAYS_NS0], alphat2[RAYS_NS0];
+} rays_axisym_params_t;
+
 /* ---- everything trace_rays reads from module state ----------------------- */
 typedef struct rays_params {
   int32_t abi_version;  /* RAYS_ABI_VERSION */
@@ -134,6 +153,8 @@ typedef struct rays_params {
   int32_t damping_model;      /* RAYS_DAMP_* */
   int32_t multi_spec_damping; /* must be 0 on the device path */
   double total_damping_limit; /* damping_m.f90:38 */
+  /* appended in ABI version 3 */
+  rays_axisym_params_t axisym;
 } rays_params_t;
 
 /* ---- library control ----------------------------------------------------------------------- */
@@ -154,6 +175,26 @@ const char* rays_hip_stop_flag_text(int stop_code);
  * compact cubic spline fsplRe(4, nx) in Fortran order == C [nx][4], on the uniform grid
  * x_min .. x_max.  The library copies it; it must be set before tracing with damping. */
 int rays_hip_set_zfun_table(const double* fspl_re, int nx, double x_min, double x_max);
+
+/* Spline tables of equilib_model = 'axisym_toroid' with magnetics_model =
+ * 'eqdsk_magnetics_spline_interp'.  Coefficient generation (PPPL pspline bcspline/cspline, not-a-knot)
+ * stays on the host -- in RAYS it is initialize_eqdsk_magnetics_spline_interp /
+ * initialize_density_spline_interp / initialize_temperature_spline_interp -- and only evaluation
+ * (bcspeval / cspeval on uniform grids) runs on the device.  All arrays are the host objects'
+ * own storage (type cube_spline_function_1D/2D, quick_cube_splines_m.f90:36-56):
+ *   psi_fspl(4,4,nr,nz) Fortran order, on r_grid(nr) x z_grid(nz);   Psi - PSIAXIS
+ *   rb_fspl(4,n_rb) on rb_grid:   T = R*Bphi
+ *   ne/te/ti_fspl(4,n) on *_grid (psiN 0..1): profiles normalised to 1 on axis; n = 0 if unused.
+ * The library copies everything; set before tracing. */
+typedef struct rays_axisym_tables {
+  int32_t nr, nz, n_rb, n_ne, n_te, n_ti;
+  const double *r_grid, *z_grid, *psi_fspl;
+  const double *rb_grid, *rb_fspl;
+  const double *ne_grid, *ne_fspl;
+  const double *te_grid, *te_fspl;
+  const double *ti_grid, *ti_fspl;
+} rays_axisym_tables_t;
+int rays_hip_set_axisym_tables(const rays_axisym_tables_t* t);
 
 /* Validates a parameter block exactly as the reference's `stop 1` configuration checks would;
  * 0 if the device path supports it. */

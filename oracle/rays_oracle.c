@@ -307,6 +307,202 @@ static int solovev_eq(const rays_params_t* P, const double rvec[3], double bvec[
 }
 
 /* --------------------------------------------------------------------------------------------
+ * PPPL-pspline evaluation on uniform grids (ilinx = iliny = 1):
+ *   cspevx / bcspevxy   splines_lib/cspeval.f90:93-160, bcspeval.f90:128-255  (cell lookup)
+ *   cspevfn / bcspevfn  cspeval.f90:205-250, bcspeval.f90:259-458              (Horner forms)
+ * Out-of-range targets: the reference clamps within 4e-7*max|x| and otherwise returns ier = 1
+ * leaving the outputs undefined; here the target is always clamped (defined behaviour, only
+ * reachable for deriv_num's perturbed points, which skip the box test).
+ * ------------------------------------------------------------------------------------------ */
+static int spl_cell(const double* x, int nx, double xget, double* dx) {
+  double z = xget;
+  if (z < x[0]) z = x[0];
+  if (z > x[nx - 1]) z = x[nx - 1];
+  const int nxm = nx - 1;
+  int ii = (int)(1 + nxm * (z - x[0]) / (x[nx - 1] - x[0]));
+  int i = ii < nxm ? ii : nxm;
+  if (i < 1) i = 1;
+  if (z < x[i - 1]) i = i - 1;
+  else if (z > x[i]) i = i + 1;
+  if (i < 1) i = 1;
+  if (i > nxm) i = nxm;
+  *dx = z - x[i - 1];
+  return i; /* 1-based cell index */
+}
+
+typedef struct {
+  int nr, nz, n_rb, n_ne, n_te, n_ti;
+  double *r_grid, *z_grid, *psi_fspl, *rb_grid, *rb_fspl, *ne_grid, *ne_fspl, *te_grid, *te_fspl,
+      *ti_grid, *ti_fspl;
+} axisym_tables;
+static axisym_tables AX;
+
+static double* dup_d(const double* p, size_t n) {
+  if (!p || !n) return NULL;
+  double* q = (double*)malloc(n * sizeof(double));
+  memcpy(q, p, n * sizeof(double));
+  return q;
+}
+
+int rays_oracle_set_axisym_tables(const rays_axisym_tables_t* t) {
+  free(AX.r_grid); free(AX.z_grid); free(AX.psi_fspl); free(AX.rb_grid); free(AX.rb_fspl);
+  free(AX.ne_grid); free(AX.ne_fspl); free(AX.te_grid); free(AX.te_fspl); free(AX.ti_grid); free(AX.ti_fspl);
+  memset(&AX, 0, sizeof AX);
+  AX.nr = t->nr; AX.nz = t->nz; AX.n_rb = t->n_rb; AX.n_ne = t->n_ne; AX.n_te = t->n_te; AX.n_ti = t->n_ti;
+  AX.r_grid = dup_d(t->r_grid, t->nr); AX.z_grid = dup_d(t->z_grid, t->nz);
+  AX.psi_fspl = dup_d(t->psi_fspl, (size_t)16 * t->nr * t->nz);
+  AX.rb_grid = dup_d(t->rb_grid, t->n_rb); AX.rb_fspl = dup_d(t->rb_fspl, (size_t)4 * t->n_rb);
+  AX.ne_grid = dup_d(t->ne_grid, t->n_ne); AX.ne_fspl = dup_d(t->ne_fspl, (size_t)4 * t->n_ne);
+  AX.te_grid = dup_d(t->te_grid, t->n_te); AX.te_fspl = dup_d(t->te_fspl, (size_t)4 * t->n_te);
+  AX.ti_grid = dup_d(t->ti_grid, t->n_ti); AX.ti_fspl = dup_d(t->ti_fspl, (size_t)4 * t->n_ti);
+  return 0;
+}
+
+/* eval_1D_fp: value and first derivative (quick_cube_splines_m.f90:105-121, cspevfn) */
+static void spl1_fp(const double* grid, const double* fspl, int n, double x, double* f, double* fp) {
+  double dx;
+  const int i = spl_cell(grid, n, x, &dx);
+  const double* c = fspl + 4 * (size_t)(i - 1);
+  *f = c[0] + dx * (c[1] + dx * (c[2] + dx * c[3]));
+  *fp = c[1] + dx * (2.0 * c[2] + dx * 3.0 * c[3]);
+}
+
+/* eval_2D_fpp (quick_cube_splines_m.f90:305-332): f, fx, fy, fxx, fxy, fyy from fspl(4,4,nx,ny) */
+static void spl2_fpp(double x, double y, double out[6]) {
+  double dx, dy;
+  const int i = spl_cell(AX.r_grid, AX.nr, x, &dx);
+  const int j = spl_cell(AX.z_grid, AX.nz, y, &dy);
+  const double* c = AX.psi_fspl + 16 * ((size_t)(i - 1) + (size_t)AX.nr * (size_t)(j - 1));
+#define F(a, b) c[((a) - 1) + 4 * ((b) - 1)]
+  out[0] = F(1,1) + dy * (F(1,2) + dy * (F(1,3) + dy * F(1,4))) +
+           dx * (F(2,1) + dy * (F(2,2) + dy * (F(2,3) + dy * F(2,4))) +
+           dx * (F(3,1) + dy * (F(3,2) + dy * (F(3,3) + dy * F(3,4))) +
+           dx * (F(4,1) + dy * (F(4,2) + dy * (F(4,3) + dy * F(4,4))))));
+  out[1] = F(2,1) + dy * (F(2,2) + dy * (F(2,3) + dy * F(2,4))) +
+           2.0 * dx * (F(3,1) + dy * (F(3,2) + dy * (F(3,3) + dy * F(3,4))) +
+           1.5 * dx * (F(4,1) + dy * (F(4,2) + dy * (F(4,3) + dy * F(4,4)))));
+  out[2] = F(1,2) + dy * (2.0 * F(1,3) + dy * 3.0 * F(1,4)) +
+           dx * (F(2,2) + dy * (2.0 * F(2,3) + dy * 3.0 * F(2,4)) +
+           dx * (F(3,2) + dy * (2.0 * F(3,3) + dy * 3.0 * F(3,4)) +
+           dx * (F(4,2) + dy * (2.0 * F(4,3) + dy * 3.0 * F(4,4)))));
+  out[3] = 2.0 * (F(3,1) + dy * (F(3,2) + dy * (F(3,3) + dy * F(3,4)))) +
+           6.0 * dx * (F(4,1) + dy * (F(4,2) + dy * (F(4,3) + dy * F(4,4))));          /* fxx */
+  out[5] = 2.0 * F(1,3) + 6.0 * dy * F(1,4) +
+           dx * (2.0 * F(2,3) + 6.0 * dy * F(2,4) +
+           dx * (2.0 * F(3,3) + 6.0 * dy * F(3,4) + dx * (2.0 * F(4,3) + 6.0 * dy * F(4,4)))); /* fyy */
+  out[4] = F(2,2) + dy * (2.0 * F(2,3) + dy * 3.0 * F(2,4)) +
+           2. * dx * (F(3,2) + dy * (2.0 * F(3,3) + dy * 3.0 * F(3,4)) +
+           1.5 * dx * (F(4,2) + dy * (2.0 * F(4,3) + dy * 3.0 * F(4,4))));              /* fxy */
+#undef F
+}
+
+/* --------------------------------------------------------------------------------------------
+ * axisym_toroid_eq + eqdsk_magnetics_spline_interp
+ *   axisym_toroid_eq_m.f90:215-362, eqdsk_magnetics_spline_interp_m.f90:206-282,
+ *   density_spline_interp_m.f90:109-130, temperature_spline_interp_m.f90
+ * ------------------------------------------------------------------------------------------ */
+static int axisym_eq(const rays_params_t* P, const double rvec[3], double bvec[3], double gbt[3][3],
+                     double* ns, double (*gradns)[3], double* ts, double (*gradts)[3], int check_box) {
+  const rays_axisym_params_t* S = &P->axisym;
+  const int nspec = P->nspec;
+  const double Tiny = 10.0e-14;
+  int err = 0;
+  const double x = rvec[0], y = rvec[1], z = rvec[2];
+  const double r = sqrt(x * x + y * y);
+  if (r < S->box_rmin - Tiny || r > S->box_rmax + Tiny) err = RAYS_STOP_AXI_R_OUT_OF_BOX;
+  if (z < S->box_zmin - Tiny || z > S->box_zmax + Tiny) err = RAYS_STOP_AXI_Z_OUT_OF_BOX;
+  if (err && check_box) return err;
+  err = 0;
+  double f6[6], RBphi, RBphiR;
+  spl2_fpp(r, z, f6);
+  const double psi = f6[0], PsiR = f6[1], PsiZ = f6[2], PsiRR = f6[3], PsiRZ = f6[4], PsiZZ = f6[5];
+  spl1_fp(AX.rb_grid, AX.rb_fspl, AX.n_rb, r, &RBphi, &RBphiR);
+  const double br = PsiZ / r, bz = -PsiR / r, bphi = RBphi / r;
+  const double gradpsi[3] = {-x * bz, -y * bz, r * br};
+  const double psiN = psi / S->psiB;
+  const double gpN[3] = {gradpsi[0] / S->psiB, gradpsi[1] / S->psiB, gradpsi[2] / S->psiB};
+  const double dbrdr = -br / r + PsiRZ / r;
+  const double dbrdz = PsiZZ / r;
+  const double dbzdr = -bz / r - PsiRR / r;
+  const double dbzdz = -PsiRZ / r;
+  const double dbphidr = (RBphiR - bphi) / r;
+  bvec[0] = br * x / r - bphi * y / r;
+  bvec[1] = br * y / r + bphi * x / r;
+  bvec[2] = bz;
+  gbt[0][0] = (dbrdr * sq(x) + br * sq(y) / r + (-dbphidr + bphi / r) * x * y) / sq(r);
+  gbt[1][0] = ((dbrdr - br / r) * x * y - dbphidr * sq(y) - bphi * sq(x) / r) / sq(r);
+  gbt[2][0] = dbrdz * x / r;
+  gbt[0][1] = ((dbrdr - br / r) * x * y + dbphidr * sq(x) + bphi * sq(y) / r) / sq(r);
+  gbt[1][1] = (dbrdr * sq(y) + br * sq(x) / r + (dbphidr - bphi / r) * x * y) / sq(r);
+  gbt[2][1] = dbrdz * y / r;
+  gbt[0][2] = dbzdr * x / r;
+  gbt[1][2] = dbzdr * y / r;
+  gbt[2][2] = dbzdz;
+  if (psiN > S->plasma_psi_limit) err = RAYS_STOP_OUT_OF_PLASMA; /* :288 */
+
+  /* density :290-312 */
+  if (S->density_prof_model == RAYS_AXI_N_CONSTANT) {
+    for (int is = 0; is <= nspec; is++) {
+      ns[is] = P->n0s[is];
+      gradns[is][0] = gradns[is][1] = gradns[is][2] = 0.;
+    }
+  } else {
+    double dens = 0., dd_psi = 0.;
+    if (S->density_prof_model == RAYS_AXI_N_PARABOLIC) {
+      parabolic_prof(psiN, S->d_scrape_off, S->alphan1, S->alphan2, &dens, &dd_psi);
+    } else { /* density_spline_interp_m.f90:109-130 (dd_psi := 0 where the reference leaves it undefined) */
+      if (psiN <= 1.0) spl1_fp(AX.ne_grid, AX.ne_fspl, AX.n_ne, psiN, &dens, &dd_psi);
+      if (dens < S->d_scrape_off) {
+        dens = S->d_scrape_off;
+        dd_psi = 0.;
+      }
+    }
+    for (int is = 0; is <= nspec; is++) {
+      ns[is] = P->n0s[is] * dens;
+      gradns[is][0] = P->n0s[is] * dd_psi * gpN[0];
+      gradns[is][1] = P->n0s[is] * dd_psi * gpN[1];
+      gradns[is][2] = P->n0s[is] * dd_psi * gpN[2];
+    }
+  }
+  /* temperature :314-354 */
+  for (int is = 0; is <= nspec; is++) {
+    ts[is] = 0.;
+    gradts[is][0] = gradts[is][1] = gradts[is][2] = 0.;
+  }
+  for (int is = 0; is <= nspec; is++) {
+    const int m = S->t_prof_model[is];
+    if (m == RAYS_AXI_T_CONSTANT) {
+      ts[is] = P->t0s[is];
+      for (int j = 0; j <= nspec; j++) gradts[j][0] = gradts[j][1] = gradts[j][2] = 0.; /* `gradts = 0.` (:328) */
+    } else if (m == RAYS_AXI_T_PARABOLIC) {
+      double t_prof, dt_dpsi;
+      parabolic_prof(psiN, S->T_scrape_off, S->alphat1[is], S->alphat2[is], &t_prof, &dt_dpsi);
+      ts[is] = P->t0s[is] * t_prof;
+      for (int i = 0; i < 3; i++) gradts[is][i] = P->t0s[is] * dt_dpsi * gpN[i];
+    } else if (m == RAYS_AXI_T_SPLINE) {
+      double Te = 0., dTe = 0., Ti = 0., dTi = 0.;
+      if (psiN <= 1.0) {
+        spl1_fp(AX.te_grid, AX.te_fspl, AX.n_te, psiN, &Te, &dTe);
+        spl1_fp(AX.ti_grid, AX.ti_fspl, AX.n_ti, psiN, &Ti, &dTi);
+      }
+      if (Te < S->T_scrape_off) { Te = S->T_scrape_off; dTe = 0.; }
+      if (Ti < S->T_scrape_off) { Ti = S->T_scrape_off; dTi = 0.; }
+      const double T = is == 0 ? Te : Ti, dT = is == 0 ? dTe : dTi;
+      ts[is] = P->t0s[is] * T;
+      for (int i = 0; i < 3; i++) gradts[is][i] = P->t0s[is] * dT * gpN[i];
+    }
+  }
+  double mn = ns[0], mt = ts[0];
+  for (int is = 1; is <= nspec; is++) {
+    if (ns[is] < mn) mn = ns[is];
+    if (ts[is] < mt) mt = ts[is];
+  }
+  if (mn < 0.) err = RAYS_STOP_NEGATIVE_DENS;
+  if (mt < 0.) err = RAYS_STOP_NEGATIVE_TEMP;
+  return check_box ? err : 0;
+}
+
+/* --------------------------------------------------------------------------------------------
  * equilibrium              equilibrium_m.f90:135-272
  * ------------------------------------------------------------------------------------------ */
 static void equilibrium(const rays_params_t* P, rf_ctx rf, const double rvec[3], eq_point* eq,
@@ -316,8 +512,10 @@ static void equilibrium(const rays_params_t* P, rf_ctx rf, const double rvec[3],
   int err;
   if (P->equilib_model == RAYS_EQ_SLAB)
     err = slab_eq(P, rvec, bvec, gbt, ns, gradns, ts, gradts, check_box);
-  else
+  else if (P->equilib_model == RAYS_EQ_SOLOVEV)
     err = solovev_eq(P, rvec, bvec, gbt, ns, gradns, ts, gradts, check_box);
+  else
+    err = axisym_eq(P, rvec, bvec, gbt, ns, gradns, ts, gradts, check_box);
   eq->err = err;
   if (err) return; /* :198-202: eq is left otherwise undefined */
 
@@ -916,6 +1114,7 @@ int rays_oracle_check_params(const rays_params_t* P) {
   if (P->nv != 7 + (P->damping_model ? 1 : 0) + (P->integrate_eq_gradients ? 5 : 0)) return 3;
   if (P->multi_spec_damping) return 5;
   if (P->damping_model == RAYS_DAMP_FUND_ECH && !zf_fspl) return 6;
+  if (P->equilib_model == RAYS_EQ_AXISYM && (!AX.psi_fspl || !AX.rb_fspl)) return 7;
   if (P->nv > RAYS_ORACLE_NV_MAX) return 3;
   if (P->equilib_model == RAYS_EQ_SOLOVEV)
     for (int is = 0; is <= P->nspec; is++)

@@ -24,12 +24,18 @@ program ref_dump_driver
     use equilibrium_m, only : equilibrium, eq_point, equilib_model
     use solovev_eq_m, only : rmaj, kappa, bphi0, iota0, outer_bound, psiB
     use zfunctions_m, only : fsplRe, zf_nx => nx, x_grid_min, x_grid_max
+    use axisym_toroid_eq_m, only : ax_rmin => box_rmin, ax_rmax => box_rmax, ax_zmin => box_zmin, &
+         & ax_zmax => box_zmax, plasma_psi_limit
+    use eqdsk_magnetics_spline_interp_m, only : Psi_profile, T_profile
+    use eqdsk_utilities_m, only : PSIBOUND
+    use density_spline_interp_m, only : ne_profile_N
+    use temperature_spline_interp_m, only : Te_profileN, Ti_profileN
     use omp_lib
     implicit none
 
     logical :: read_input = .true.
     character(len=256) :: fname, sval
-    integer :: u, u2, stat, probe_stride, reps, irep, iray, j, nprobe, is
+    integer :: u, u2, stat, probe_stride, reps, irep, iray, j, nprobe, is, n_ne, n_te, n_ti
     real(kind=rkind) :: t0, t1, wall, resid, s
     real(kind=rkind), allocatable :: v(:), dvds(:)
     real(kind=rkind) :: dddx(3), dddk(3), dddw, ndx(3), ndk(3), ndw, nvec(3)
@@ -125,6 +131,24 @@ program ref_dump_driver
        write(u2) zf_nx
        write(u2) x_grid_min, x_grid_max
        write(u2) fsplRe
+       close(u2)
+    end if
+
+    call get_environment_variable('RAYS_DUMP_AXISYM', sval, status=stat)
+    if (stat == 0 .and. len_trim(sval) > 0 .and. trim(equilib_model) == 'axisym_toroid') then
+       ! spline tables of the eqdsk equilibrium (host objects of quick_cube_splines_m)
+       open(newunit=u2, file=trim(sval), access='stream', form='unformatted', status='replace')
+       n_ne = 0 ; n_te = 0 ; n_ti = 0
+       if (allocated(ne_profile_N%fspl)) n_ne = ne_profile_N%nx
+       if (allocated(Te_profileN%fspl)) n_te = Te_profileN%nx
+       if (allocated(Ti_profileN%fspl)) n_ti = Ti_profileN%nx
+       write(u2) Psi_profile%nx, Psi_profile%ny, T_profile%nx, n_ne, n_te, n_ti
+       write(u2) ax_rmin, ax_rmax, ax_zmin, ax_zmax, plasma_psi_limit, PSIBOUND
+       write(u2) Psi_profile%x_grid, Psi_profile%y_grid, Psi_profile%fspl
+       write(u2) T_profile%x_grid, T_profile%fspl
+       if (n_ne > 0) write(u2) ne_profile_N%x_grid, ne_profile_N%fspl
+       if (n_te > 0) write(u2) Te_profileN%x_grid, Te_profileN%fspl
+       if (n_ti > 0) write(u2) Ti_profileN%x_grid, Ti_profileN%fspl
        close(u2)
     end if
 

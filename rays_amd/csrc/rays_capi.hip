@@ -27,6 +27,10 @@ RAYS_DECL_ENTRIES(1, 0, 0)
 RAYS_DECL_ENTRIES(1, 0, 1)
 RAYS_DECL_ENTRIES(1, 1, 0)
 RAYS_DECL_ENTRIES(1, 1, 1)
+RAYS_DECL_ENTRIES(0, 2, 0)
+RAYS_DECL_ENTRIES(0, 2, 1)
+RAYS_DECL_ENTRIES(1, 2, 0)
+RAYS_DECL_ENTRIES(1, 2, 1)
 hipError_t launch_pack(bool pack, int nray, int nv, int nstep_max, const int32_t* npoints,
                        const long long* offsets, double* ray_vec, double* residual, double* packed_vec,
                        double* packed_res, hipStream_t stream);
@@ -69,6 +73,9 @@ const FlagText kFlags[] = {
     {RAYS_STOP_NEGATIVE_TEMP, "negative_temp"},
     {RAYS_STOP_R_OUT_OF_BOX, "R out_of_box"},
     {RAYS_STOP_Z_OUT_OF_BOX, "z out_of_box"},
+    {RAYS_STOP_AXI_R_OUT_OF_BOX, "R_out_of_box"},
+    {RAYS_STOP_AXI_Z_OUT_OF_BOX, "Z_out_of_box"},
+    {RAYS_STOP_OUT_OF_PLASMA, "out_of_plasma"},
     {RAYS_STOP_INFINITE_VG_RHS, "infinite Vg"},
     {RAYS_STOP_RAY_STALLED, "ray stalled"},
     {RAYS_STOP_DISP_RESIDUAL, "dispersion_residual"},
@@ -87,9 +94,9 @@ const FlagText kFlags[] = {
 const rays::KernelEntry* find_kernel(const rays_params_t& p) {
   using namespace rays;
   typedef const KernelEntry* (*Getter)(int*);
-  static const Getter getters[2][2][2] = {
-      {{rays_entries_0_0_0, rays_entries_0_0_1}, {rays_entries_0_1_0, rays_entries_0_1_1}},
-      {{rays_entries_1_0_0, rays_entries_1_0_1}, {rays_entries_1_1_0, rays_entries_1_1_1}}};
+  static const Getter getters[2][3][2] = {
+      {{rays_entries_0_0_0, rays_entries_0_0_1}, {rays_entries_0_1_0, rays_entries_0_1_1}, {rays_entries_0_2_0, rays_entries_0_2_1}},
+      {{rays_entries_1_0_0, rays_entries_1_0_1}, {rays_entries_1_1_0, rays_entries_1_1_1}, {rays_entries_1_2_0, rays_entries_1_2_1}}};
   int n = 0;
   const KernelEntry* e = getters[p.ode_solver][p.equilib_model][p.ray_deriv](&n);
   for (int i = 0; i < n; i++)
@@ -126,6 +133,42 @@ int get_zfun_device(const double** out) {
     z.version = g_zfun.version;
   }
   *out = z.ptr;
+  return 0;
+}
+
+// axisym_toroid spline tables: one packed host copy, lazily uploaded per device
+struct AxisymHost {
+  std::vector<double> blob;  // all arrays back to back
+  size_t off[11] = {0};      // r_grid z_grid psi rb_grid rb_fspl ne_grid ne_fspl te_grid te_fspl ti_grid ti_fspl
+  int nr = 0, nz = 0, n_rb = 0, n_ne = 0, n_te = 0, n_ti = 0;
+  unsigned long long version = 0;
+};
+AxisymHost g_axi;
+std::vector<ZfunDevice> g_axi_dev;
+
+int get_axisym_device(rays::DevParams* D) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_axi.nr <= 1 || g_axi.nz <= 1 || g_axi.n_rb <= 1)
+    return fail("equilib_model = 'axisym_toroid' needs rays_hip_set_axisym_tables() first");
+  if ((int)g_axi_dev.size() <= dev) g_axi_dev.resize(dev + 1);
+  ZfunDevice& z = g_axi_dev[dev];
+  if (z.version != g_axi.version) {
+    if (z.ptr) (void)hipFree(z.ptr);
+    z.ptr = nullptr;
+    HIP_TRY(hipMalloc(&z.ptr, sizeof(double) * g_axi.blob.size()));
+    HIP_TRY(hipMemcpy(z.ptr, g_axi.blob.data(), sizeof(double) * g_axi.blob.size(), hipMemcpyHostToDevice));
+    z.version = g_axi.version;
+  }
+  const double* b = z.ptr;
+  D->a_nr = g_axi.nr; D->a_nz = g_axi.nz; D->a_n_rb = g_axi.n_rb;
+  D->a_n_ne = g_axi.n_ne; D->a_n_te = g_axi.n_te; D->a_n_ti = g_axi.n_ti;
+  D->a_r_grid = b + g_axi.off[0]; D->a_z_grid = b + g_axi.off[1]; D->a_psi_fspl = b + g_axi.off[2];
+  D->a_rb_grid = b + g_axi.off[3]; D->a_rb_fspl = b + g_axi.off[4];
+  D->a_ne_grid = b + g_axi.off[5]; D->a_ne_fspl = b + g_axi.off[6];
+  D->a_te_grid = b + g_axi.off[7]; D->a_te_fspl = b + g_axi.off[8];
+  D->a_ti_grid = b + g_axi.off[9]; D->a_ti_fspl = b + g_axi.off[10];
   return 0;
 }
 
@@ -178,6 +221,33 @@ int rays_hip_set_zfun_table(const double* fspl_re, int nx, double x_min, double 
   return 0;
 }
 
+int rays_hip_set_axisym_tables(const rays_axisym_tables_t* t) {
+  if (!t || t->nr < 2 || t->nz < 2 || t->n_rb < 2 || !t->r_grid || !t->z_grid || !t->psi_fspl || !t->rb_grid ||
+      !t->rb_fspl)
+    return fail("rays_hip_set_axisym_tables: bad tables");
+  if ((t->n_ne > 0 && (!t->ne_grid || !t->ne_fspl)) || (t->n_te > 0 && (!t->te_grid || !t->te_fspl)) ||
+      (t->n_ti > 0 && (!t->ti_grid || !t->ti_fspl)))
+    return fail("rays_hip_set_axisym_tables: profile table pointers missing");
+  std::lock_guard<std::mutex> lk(g_mu);
+  AxisymHost& h = g_axi;
+  h.blob.clear();
+  const double* src[11] = {t->r_grid, t->z_grid, t->psi_fspl, t->rb_grid, t->rb_fspl, t->ne_grid, t->ne_fspl,
+                           t->te_grid, t->te_fspl, t->ti_grid, t->ti_fspl};
+  const size_t len[11] = {(size_t)t->nr, (size_t)t->nz, (size_t)16 * t->nr * t->nz, (size_t)t->n_rb,
+                          (size_t)4 * t->n_rb, (size_t)(t->n_ne > 0 ? t->n_ne : 0), (size_t)4 * (t->n_ne > 0 ? t->n_ne : 0),
+                          (size_t)(t->n_te > 0 ? t->n_te : 0), (size_t)4 * (t->n_te > 0 ? t->n_te : 0),
+                          (size_t)(t->n_ti > 0 ? t->n_ti : 0), (size_t)4 * (t->n_ti > 0 ? t->n_ti : 0)};
+  for (int k = 0; k < 11; k++) {
+    h.off[k] = h.blob.size();
+    if (len[k]) h.blob.insert(h.blob.end(), src[k], src[k] + len[k]);
+    while (h.blob.size() % 16) h.blob.push_back(0.);  // keep every table 128-B aligned
+  }
+  h.nr = t->nr; h.nz = t->nz; h.n_rb = t->n_rb;
+  h.n_ne = t->n_ne > 0 ? t->n_ne : 0; h.n_te = t->n_te > 0 ? t->n_te : 0; h.n_ti = t->n_ti > 0 ? t->n_ti : 0;
+  h.version++;
+  return 0;
+}
+
 int rays_hip_sizeof_params(void) { return (int)sizeof(rays_params_t); }
 
 int rays_hip_device_count(void) {
@@ -221,8 +291,8 @@ int rays_hip_check_params(const rays_params_t* p) {
     return fail("EQN_RAY: invalid value, ray_deriv_name");  // eqn_ray.f90:120-122
   if (p->ray_param != RAYS_PARAM_ARCL && p->ray_param != RAYS_PARAM_TIME)
     return fail("EQN_RAY: invalid ray parameter");  // eqn_ray.f90:183-185
-  if (p->equilib_model != RAYS_EQ_SLAB && p->equilib_model != RAYS_EQ_SOLOVEV)
-    return fail("equilibrium_m: invalid equilibrium model (device path: slab | solovev)");
+  if (p->equilib_model != RAYS_EQ_SLAB && p->equilib_model != RAYS_EQ_SOLOVEV && p->equilib_model != RAYS_EQ_AXISYM)
+    return fail("equilibrium_m: invalid equilibrium model (device path: slab | solovev | axisym_toroid)");
   if (p->damping_model != RAYS_DAMP_NONE && p->damping_model != RAYS_DAMP_FUND_ECH)
     return fail("damping: Unimplemented damping model");  // damping_m.f90:103-106
   if (p->multi_spec_damping) return fail("rays_hip: multi_spec_damping is not on the device path");
@@ -235,6 +305,16 @@ int rays_hip_check_params(const rays_params_t* p) {
     for (int is = 0; is <= p->nspec; is++)
       if (p->solovev.t_prof_model[is] != RAYS_SOLOVEV_T_ZERO && p->solovev.t_prof_model[is] != RAYS_SOLOVEV_T_PARABOLIC)
         return fail("SOLOVEV: t_prof_model must be 'zero' or 'parabolic' ('constant' leaves ts undefined in the reference)");
+  } else if (p->equilib_model == RAYS_EQ_AXISYM) {
+    const rays_axisym_params_t& a = p->axisym;
+    if (a.magnetics_model != RAYS_AXI_MAG_EQDSK_SPLINE)
+      return fail("axisym_toroid: only magnetics_model = 'eqdsk_magnetics_spline_interp' is on the device path");
+    if (a.density_prof_model < 0 || a.density_prof_model > RAYS_AXI_N_SPLINE)
+      return fail("axisym_toroid_eq: Unknown density_prof_model");
+    for (int is = 0; is <= p->nspec; is++)
+      if (a.t_prof_model[is] < 0 || a.t_prof_model[is] > RAYS_AXI_T_SPLINE)
+        return fail("axisym_toroid_eq: Unknown temperature_prof_model");
+    if (!(a.psiB != 0.)) return fail("axisym_toroid: psiB (PSIBOUND - PSIAXIS) is zero");
   } else {
     const rays_slab_params_t& s = p->slab;
     if (s.bx_prof_model != RAYS_SLAB_BX_ZERO) return fail("SLAB: invalid bx_prof_model");
@@ -298,6 +378,16 @@ int rays_hip_trace_device(const rays_params_t* p, int nray, const double* d_rvec
     D.zf_nx = g_zfun.nx;
     D.zf_xmin = g_zfun.xmin;
     D.zf_xmax = g_zfun.xmax;
+  }
+  if (p->equilib_model == RAYS_EQ_AXISYM) {
+    rc = get_axisym_device(&D);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const bool need_ne = p->axisym.density_prof_model == RAYS_AXI_N_SPLINE && g_axi.n_ne < 2;
+    bool need_t = false;
+    for (int is = 0; is <= p->nspec; is++)
+      if (p->axisym.t_prof_model[is] == RAYS_AXI_T_SPLINE && (g_axi.n_te < 2 || g_axi.n_ti < 2)) need_t = true;
+    if (need_ne || need_t) return fail("axisym_toroid: spline profile model selected but its table was not set");
   }
   int grid = 0;
   hipError_t e = find_kernel(*p)->launch(D, A, stream, &grid);
@@ -452,7 +542,11 @@ int rays_hip_probe(const rays_params_t* p, int n, const double* v, double* cold7
   HIP_TRY(hipMalloc(&d_r, sizeof(double) * n));
   HIP_TRY(hipMalloc(&d_k, sizeof(int) * 4 * n));
   HIP_TRY(hipMemcpy(d_v, v, sizeof(double) * nv * n, hipMemcpyHostToDevice));
-  const rays::DevParams D = make_dev_params(*p);
+  rays::DevParams D = make_dev_params(*p);
+  if (p->equilib_model == RAYS_EQ_AXISYM) {
+    rc = get_axisym_device(&D);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(rays::probe_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, D, p->equilib_model,
                      p->nspec + 1, p->nv, n, d_v, d_c, d_n, d_f, d_r, d_k);
   HIP_TRY(hipGetLastError());

@@ -34,6 +34,14 @@ struct DevParams {
   int damping_model, zf_nx;                 // damping_m.f90:30-40; Z-function spline grid size
   double total_damping_limit, zf_xmin, zf_xmax;
   const double* zf_fspl;                    // device pointer: fsplRe[nx][4] (zfunctions_m.f90)
+  // axisym_toroid + eqdsk spline magnetics (axisym_toroid_eq_m.f90, eqdsk_magnetics_spline_interp_m.f90)
+  int a_n_model, a_nr, a_nz, a_n_rb, a_n_ne, a_n_te, a_n_ti;
+  int a_t_model[RAYS_NS0];
+  double a_box_rmin, a_box_rmax, a_box_zmin, a_box_zmax, a_psi_limit, a_psiB, a_inv_psiB;
+  double a_an1, a_an2, a_d_scrape, a_T_scrape;
+  double a_at1[RAYS_NS0], a_at2[RAYS_NS0];
+  const double *a_r_grid, *a_z_grid, *a_psi_fspl, *a_rb_grid, *a_rb_fspl, *a_ne_grid, *a_ne_fspl,
+      *a_te_grid, *a_te_fspl, *a_ti_grid, *a_ti_fspl;  // device pointers (L2-resident tables)
   double ds, s_max, omgrf, k0, clight, eps0, resid_limit;
   double omgrf2;               // omgrf**2                      equilibrium_m.f90:264
   double two_over_k0;          // 2./k0                         deriv_cold.f90:51
@@ -377,6 +385,192 @@ RAYS_DEV int solovev_fields(const DevParams& P, const double rvec[3], double bve
   return err;
 }
 
+// ---------------------------------------------------------------------------------------------
+// PPPL-pspline evaluation on uniform grids (cspevx/bcspevxy cell lookup + cspevfn/bcspevfn Horner
+// forms; splines_lib/cspeval.f90, bcspeval.f90).  Targets are clamped to the grid (the reference
+// clamps within 4e-7*max|x| and otherwise leaves the outputs undefined).  Tables live in global
+// memory: 16 doubles per bicubic cell (128 B = one cache line), 4 per cubic cell; neighbouring rays
+// hit the same or adjacent cells, so they stay L2-resident (65x65 cells = 540 KB).
+// ---------------------------------------------------------------------------------------------
+RAYS_DEV int spl_cell(const double* __restrict__ x, int nx, double xget, double& dx) {
+  const double x1 = x[0], xn = x[nx - 1];
+  double z = xget;
+  if (z < x1) z = x1;
+  if (z > xn) z = xn;
+  const int nxm = nx - 1;
+  int i = (int)(1 + nxm * (z - x1) / (xn - x1));
+  i = i < nxm ? i : nxm;
+  i = i < 1 ? 1 : i;
+  if (z < x[i - 1]) i = i - 1;
+  else if (z > x[i]) i = i + 1;
+  i = i < 1 ? 1 : (i > nxm ? nxm : i);
+  dx = z - x[i - 1];
+  return i;
+}
+
+RAYS_DEV void spl1_fp(const double* __restrict__ grid, const double* __restrict__ fspl, int n, double x,
+                      double& f, double& fp) {
+  double dx;
+  const int i = spl_cell(grid, n, x, dx);
+  const double* c = fspl + 4 * (long long)(i - 1);
+  const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+  f = c0 + dx * (c1 + dx * (c2 + dx * c3));
+  fp = c1 + dx * (2.0 * c2 + dx * 3.0 * c3);
+}
+
+// eval_2D_fpp: f, fx, fy, fxx, fxy, fyy (quick_cube_splines_m.f90:305-332, bcspevfn ict = 1,1,1,1,1,1)
+RAYS_DEV void spl2_fpp(const DevParams& P, double x, double y, double out[6]) {
+  double dx, dy;
+  const int i = spl_cell(P.a_r_grid, P.a_nr, x, dx);
+  const int j = spl_cell(P.a_z_grid, P.a_nz, y, dy);
+  const double* c = P.a_psi_fspl + 16 * ((long long)(i - 1) + (long long)P.a_nr * (long long)(j - 1));
+  double F[4][4];  // F[a-1][b-1] = f(a,b,i,j)
+#pragma unroll
+  for (int b = 0; b < 4; b++)
+#pragma unroll
+    for (int a = 0; a < 4; a++) F[a][b] = c[a + 4 * b];
+  out[0] = F[0][0] + dy * (F[0][1] + dy * (F[0][2] + dy * F[0][3])) +
+           dx * (F[1][0] + dy * (F[1][1] + dy * (F[1][2] + dy * F[1][3])) +
+           dx * (F[2][0] + dy * (F[2][1] + dy * (F[2][2] + dy * F[2][3])) +
+           dx * (F[3][0] + dy * (F[3][1] + dy * (F[3][2] + dy * F[3][3])))));
+  out[1] = F[1][0] + dy * (F[1][1] + dy * (F[1][2] + dy * F[1][3])) +
+           2.0 * dx * (F[2][0] + dy * (F[2][1] + dy * (F[2][2] + dy * F[2][3])) +
+           1.5 * dx * (F[3][0] + dy * (F[3][1] + dy * (F[3][2] + dy * F[3][3]))));
+  out[2] = F[0][1] + dy * (2.0 * F[0][2] + dy * 3.0 * F[0][3]) +
+           dx * (F[1][1] + dy * (2.0 * F[1][2] + dy * 3.0 * F[1][3]) +
+           dx * (F[2][1] + dy * (2.0 * F[2][2] + dy * 3.0 * F[2][3]) +
+           dx * (F[3][1] + dy * (2.0 * F[3][2] + dy * 3.0 * F[3][3]))));
+  out[3] = 2.0 * (F[2][0] + dy * (F[2][1] + dy * (F[2][2] + dy * F[2][3]))) +
+           6.0 * dx * (F[3][0] + dy * (F[3][1] + dy * (F[3][2] + dy * F[3][3])));  // fxx
+  out[5] = 2.0 * F[0][2] + 6.0 * dy * F[0][3] +
+           dx * (2.0 * F[1][2] + 6.0 * dy * F[1][3] +
+           dx * (2.0 * F[2][2] + 6.0 * dy * F[2][3] + dx * (2.0 * F[3][2] + 6.0 * dy * F[3][3])));  // fyy
+  out[4] = F[1][1] + dy * (2.0 * F[1][2] + dy * 3.0 * F[1][3]) +
+           2. * dx * (F[2][1] + dy * (2.0 * F[2][2] + dy * 3.0 * F[2][3]) +
+           1.5 * dx * (F[3][1] + dy * (2.0 * F[3][2] + dy * 3.0 * F[3][3])));  // fxy
+}
+
+// axisym_toroid_eq + eqdsk_magnetics_spline_interp
+//   axisym_toroid_eq_m.f90:215-362, eqdsk_magnetics_spline_interp_m.f90:206-282,
+//   density_spline_interp_m.f90:109-130, temperature_spline_interp_m.f90
+template <int NS>
+RAYS_DEV int axisym_fields(const DevParams& P, const double rvec[3], double bvec[3], double gbt[3][3],
+                           double ns[NS], double gradns[NS][3], double ts[NS], double gradts[NS][3],
+                           bool check_box) {
+  constexpr double Tiny = 10.0e-14;
+  int err = 0;
+  const double x = rvec[0], y = rvec[1], z = rvec[2];
+  const double r = sqrt(x * x + y * y);
+  if (r < P.a_box_rmin - Tiny || r > P.a_box_rmax + Tiny) err = RAYS_STOP_AXI_R_OUT_OF_BOX;  // :261-264
+  if (z < P.a_box_zmin - Tiny || z > P.a_box_zmax + Tiny) err = RAYS_STOP_AXI_Z_OUT_OF_BOX;  // :265-268
+  const bool boxed = check_box && err != 0;  // reference returns here; fields below are then unused
+  double f6[6], RBphi, RBphiR;
+  spl2_fpp(P, r, z, f6);
+  const double psi = f6[0], PsiR = f6[1], PsiZ = f6[2], PsiRR = f6[3], PsiRZ = f6[4], PsiZZ = f6[5];
+  spl1_fp(P.a_rb_grid, P.a_rb_fspl, P.a_n_rb, r, RBphi, RBphiR);
+  const Recip Rr = make_recip(r), Rr2 = make_recip(sq(r));
+  const Recip RpsiB = const_recip(P.a_psiB, P.a_inv_psiB);
+  const double br = div(PsiZ, Rr), bz = div(-PsiR, Rr), bphi = div(RBphi, Rr);
+  const double gradpsi[3] = {-x * bz, -y * bz, r * br};
+  const double psiN = div(psi, RpsiB);
+  const double gpN[3] = {div(gradpsi[0], RpsiB), div(gradpsi[1], RpsiB), div(gradpsi[2], RpsiB)};
+  const double br_r = div(br, Rr), bphi_r = div(bphi, Rr);
+  const double dbrdr = -br_r + div(PsiRZ, Rr);
+  const double dbrdz = div(PsiZZ, Rr);
+  const double dbzdr = div(-bz, Rr) - div(PsiRR, Rr);
+  const double dbzdz = div(-PsiRZ, Rr);
+  const double dbphidr = div(RBphiR - bphi, Rr);
+  bvec[0] = div(br * x, Rr) - div(bphi * y, Rr);
+  bvec[1] = div(br * y, Rr) + div(bphi * x, Rr);
+  bvec[2] = bz;
+  const double x2 = sq(x), y2 = sq(y);
+  gbt[0][0] = div(dbrdr * x2 + div(br * y2, Rr) + (-dbphidr + bphi_r) * x * y, Rr2);
+  gbt[1][0] = div((dbrdr - br_r) * x * y - dbphidr * y2 - div(bphi * x2, Rr), Rr2);
+  gbt[2][0] = div(dbrdz * x, Rr);
+  gbt[0][1] = div((dbrdr - br_r) * x * y + dbphidr * x2 + div(bphi * y2, Rr), Rr2);
+  gbt[1][1] = div(dbrdr * y2 + div(br * x2, Rr) + (dbphidr - bphi_r) * x * y, Rr2);
+  gbt[2][1] = div(dbrdz * y, Rr);
+  gbt[0][2] = div(dbzdr * x, Rr);
+  gbt[1][2] = div(dbzdr * y, Rr);
+  gbt[2][2] = dbzdz;
+  if (!boxed) err = 0;
+  if (!boxed && psiN > P.a_psi_limit) err = RAYS_STOP_OUT_OF_PLASMA;  // :288
+
+  if (P.a_n_model == RAYS_AXI_N_CONSTANT) {  // :290-312
+#pragma unroll
+    for (int is = 0; is < NS; is++) {
+      ns[is] = P.n0s[is];
+      gradns[is][0] = gradns[is][1] = gradns[is][2] = 0.;
+    }
+  } else {
+    double dens = 0., dd_psi = 0.;
+    if (P.a_n_model == RAYS_AXI_N_PARABOLIC) {
+      parabolic_prof(psiN, P.a_d_scrape, P.a_an1, P.a_an2, dens, dd_psi);
+    } else {
+      if (psiN <= 1.0) spl1_fp(P.a_ne_grid, P.a_ne_fspl, P.a_n_ne, psiN, dens, dd_psi);
+      if (dens < P.a_d_scrape) {
+        dens = P.a_d_scrape;
+        dd_psi = 0.;
+      }
+    }
+#pragma unroll
+    for (int is = 0; is < NS; is++) {
+      ns[is] = P.n0s[is] * dens;
+      const double c = P.n0s[is] * dd_psi;
+      gradns[is][0] = c * gpN[0];
+      gradns[is][1] = c * gpN[1];
+      gradns[is][2] = c * gpN[2];
+    }
+  }
+#pragma unroll
+  for (int is = 0; is < NS; is++) {
+    ts[is] = 0.;
+    gradts[is][0] = gradts[is][1] = gradts[is][2] = 0.;
+  }
+#pragma unroll
+  for (int is = 0; is < NS; is++) {  // :314-354
+    const int m = P.a_t_model[is];
+    if (m == RAYS_AXI_T_CONSTANT) {
+      ts[is] = P.t0s[is];
+#pragma unroll
+      for (int j = 0; j < NS; j++) gradts[j][0] = gradts[j][1] = gradts[j][2] = 0.;  // `gradts = 0.` (:328)
+    } else if (m == RAYS_AXI_T_PARABOLIC) {
+      double t_prof, dt_dpsi;
+      parabolic_prof(psiN, P.a_T_scrape, P.a_at1[is], P.a_at2[is], t_prof, dt_dpsi);
+      ts[is] = P.t0s[is] * t_prof;
+      const double c = P.t0s[is] * dt_dpsi;
+      gradts[is][0] = c * gpN[0];
+      gradts[is][1] = c * gpN[1];
+      gradts[is][2] = c * gpN[2];
+    } else if (m == RAYS_AXI_T_SPLINE) {
+      double Te = 0., dTe = 0., Ti = 0., dTi = 0.;
+      if (psiN <= 1.0) {
+        spl1_fp(P.a_te_grid, P.a_te_fspl, P.a_n_te, psiN, Te, dTe);
+        spl1_fp(P.a_ti_grid, P.a_ti_fspl, P.a_n_ti, psiN, Ti, dTi);
+      }
+      if (Te < P.a_T_scrape) { Te = P.a_T_scrape; dTe = 0.; }
+      if (Ti < P.a_T_scrape) { Ti = P.a_T_scrape; dTi = 0.; }
+      const double T = is == 0 ? Te : Ti, dT = is == 0 ? dTe : dTi;
+      ts[is] = P.t0s[is] * T;
+      const double c = P.t0s[is] * dT;
+      gradts[is][0] = c * gpN[0];
+      gradts[is][1] = c * gpN[1];
+      gradts[is][2] = c * gpN[2];
+    }
+  }
+  if (check_box && !boxed) {  // :358-359
+    double mn = ns[0], mt = ts[0];
+#pragma unroll
+    for (int is = 1; is < NS; is++) {
+      if (ns[is] < mn) mn = ns[is];
+      if (ts[is] < mt) mt = ts[is];
+    }
+    if (mn < 0.) err = RAYS_STOP_NEGATIVE_DENS;
+    if (mt < 0.) err = RAYS_STOP_NEGATIVE_TEMP;
+  }
+  return check_box ? err : 0;
+}
+
 // equilibrium               equilibrium_m.f90:135-272
 // omgrf / omgrf2 are arguments because deriv_num re-evaluates the equilibrium at omgrf(1 +- delta/2)
 // (deriv_num.f90:72-79); on the device these are per-call values, which also removes the
@@ -388,8 +582,10 @@ RAYS_DEV void equilibrium(const DevParams& P, const Recip& Romgrf, const Recip& 
   int err;
   if (EQ == RAYS_EQ_SLAB)
     err = slab_fields<NS>(P, rvec, eq.bvec, eq.gbt, ns, gradns, ts, gradts, check_box);
-  else
+  else if (EQ == RAYS_EQ_SOLOVEV)
     err = solovev_fields<NS>(P, rvec, eq.bvec, eq.gbt, ns, gradns, ts, gradts, check_box);
+  else
+    err = axisym_fields<NS>(P, rvec, eq.bvec, eq.gbt, ns, gradns, ts, gradts, check_box);
   eq.err = err;
   // When err != 0 the reference returns with eq undefined (:198-202).  We still fill it (fields
   // evaluated at the out-of-box point): callers that stop on err never read it, and check_save,

@@ -1,5 +1,5 @@
 // rays_inst.hip -- kernel instantiations.  Compiled once per (solver, equilibrium, derivative)
-// group:  -DRAYS_INST_SOLVER={0,1} -DRAYS_INST_EQ={0,1} -DRAYS_INST_DERIV={0,1}
+// group:  -DRAYS_INST_SOLVER={0,1} -DRAYS_INST_EQ={0,1,2} -DRAYS_INST_DERIV={0,1}
 // Each group instantiates the species counts NS = 1..6 (nspec = 0..5, species_m.f90:25) and
 // nv = 7 | 12 (integrate_eq_gradients) and 8 | 13 (+ damping) (ode_m.f90:160-173).
 #include "rays_launch.hpp"

@@ -51,6 +51,8 @@ __global__ void probe_kernel(const DevParams P, int eq, int ns, int nv, int n, c
   RAYS_PROBE(0, 3)
   RAYS_PROBE(1, 2)
   RAYS_PROBE(1, 3)
+  RAYS_PROBE(2, 2)
+  RAYS_PROBE(2, 3)
 #undef RAYS_PROBE
 }
 

@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-from .params import RaysParams
+from .params import AxisymTables, RaysParams, axisym_tables_struct
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librays_hip.so")
@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "librays_hip.so")
 # every symbol include/rays_hip.h declares
 EXPORTED_SYMBOLS = (
     "rays_hip_init", "rays_hip_finalize", "rays_hip_device_count", "rays_hip_sizeof_params",
-    "rays_hip_last_error", "rays_hip_set_zfun_table",
+    "rays_hip_last_error", "rays_hip_set_zfun_table", "rays_hip_set_axisym_tables",
     "rays_hip_stop_flag_text", "rays_hip_check_params", "rays_hip_trace", "rays_hip_trace_device",
     "rays_hip_kernel_name", "rays_hip_probe", "rays_hip_pack_device", "rays_hip_unpack_device",
 )
@@ -55,6 +55,8 @@ def load():
     lib.rays_hip_stop_flag_text.argtypes = [C.c_int]
     lib.rays_hip_set_zfun_table.restype = C.c_int
     lib.rays_hip_set_zfun_table.argtypes = [dp, C.c_int, C.c_double, C.c_double]
+    lib.rays_hip_set_axisym_tables.restype = C.c_int
+    lib.rays_hip_set_axisym_tables.argtypes = [C.POINTER(AxisymTables)]
     lib.rays_hip_check_params.restype = C.c_int
     lib.rays_hip_check_params.argtypes = [pp]
     lib.rays_hip_kernel_name.restype = C.c_char_p
@@ -103,6 +105,12 @@ def set_zfun_table(fspl_re=None, x_min=None, x_max=None):
     _check(load().rays_hip_set_zfun_table(_dp(fspl_re), len(fspl_re), float(x_min), float(x_max)),
            "rays_hip_set_zfun_table")
     _zfun_set = True
+
+
+def set_axisym_tables(tab: dict):
+    """Hand the host-built spline tables of an eqdsk equilibrium to the library (copied)."""
+    t, keep = axisym_tables_struct(tab)
+    _check(load().rays_hip_set_axisym_tables(C.byref(t)), "rays_hip_set_axisym_tables")
 
 
 def ensure_tables(p: RaysParams):

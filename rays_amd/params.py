@@ -15,12 +15,15 @@ from typing import Any, Dict
 import numpy as np
 
 NS0 = 6  # species_m.f90:25 nspec0 = 5 -> arrays 0:5
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ODE = {"RK4_ODE": 0, "SG_ODE": 1}
 DERIV = {"cold": 0, "numerical": 1}
 RAY_PARAM = {"arcl": 0, "time": 1}
-EQUILIB = {"slab": 0, "solovev": 1}
+EQUILIB = {"slab": 0, "solovev": 1, "axisym_toroid": 2}
+AXI_MAGNETICS = {"eqdsk_magnetics_spline_interp": 0}
+AXI_N = {"constant": 0, "parabolic": 1, "density_spline_interp": 2}
+AXI_T = {"zero": 0, "constant": 1, "parabolic": 2, "temperature_spline_interp": 3}
 SLAB_BX = {"zero": 0}
 SLAB_BY = {"zero": 0, "constant": 1, "toroid": 2, "linear_shear": 3}
 SLAB_BZ = {"constant": 0, "toroid": 1, "linear": 2, "linear_2": 3}
@@ -42,6 +45,9 @@ STOP_FLAG_TEXT = {
     14: "negative_temp",
     20: "R out_of_box",
     21: "z out_of_box",
+    22: "R_out_of_box",
+    23: "Z_out_of_box",
+    24: "out_of_plasma",
     30: "infinite Vg",
     31: "ray stalled",
     40: "dispersion_residual",
@@ -86,6 +92,62 @@ class SolovevParams(C.Structure):
     ]
 
 
+class AxisymParams(C.Structure):
+    _fields_ = [
+        ("magnetics_model", C.c_int32), ("density_prof_model", C.c_int32),
+        ("t_prof_model", C.c_int32 * NS0),
+        ("box_rmin", C.c_double), ("box_rmax", C.c_double),
+        ("box_zmin", C.c_double), ("box_zmax", C.c_double),
+        ("plasma_psi_limit", C.c_double), ("psiB", C.c_double),
+        ("alphan1", C.c_double), ("alphan2", C.c_double),
+        ("d_scrape_off", C.c_double), ("T_scrape_off", C.c_double),
+        ("alphat1", C.c_double * NS0), ("alphat2", C.c_double * NS0),
+    ]
+
+
+class AxisymTables(C.Structure):
+    """ctypes image of rays_axisym_tables_t."""
+
+    _fields_ = [
+        ("nr", C.c_int32), ("nz", C.c_int32), ("n_rb", C.c_int32), ("n_ne", C.c_int32),
+        ("n_te", C.c_int32), ("n_ti", C.c_int32),
+        ("r_grid", C.POINTER(C.c_double)), ("z_grid", C.POINTER(C.c_double)),
+        ("psi_fspl", C.POINTER(C.c_double)),
+        ("rb_grid", C.POINTER(C.c_double)), ("rb_fspl", C.POINTER(C.c_double)),
+        ("ne_grid", C.POINTER(C.c_double)), ("ne_fspl", C.POINTER(C.c_double)),
+        ("te_grid", C.POINTER(C.c_double)), ("te_fspl", C.POINTER(C.c_double)),
+        ("ti_grid", C.POINTER(C.c_double)), ("ti_fspl", C.POINTER(C.c_double)),
+    ]
+
+
+def axisym_tables_struct(tab: Dict[str, Any]):
+    """dict of numpy arrays (keys r_grid, z_grid, psi_fspl, rb_grid, rb_fspl[, ne_*, te_*, ti_*]) ->
+    (AxisymTables, keepalive list)."""
+    t = AxisymTables()
+    keep = []
+
+    def put(name):
+        a = tab.get(name)
+        if a is None or len(a) == 0:
+            return 0
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        keep.append(a)
+        setattr(t, name, a.ctypes.data_as(C.POINTER(C.c_double)))
+        return len(a)
+
+    t.nr, t.nz = put("r_grid"), put("z_grid")
+    put("psi_fspl")
+    t.n_rb = put("rb_grid")
+    put("rb_fspl")
+    t.n_ne = put("ne_grid")
+    put("ne_fspl")
+    t.n_te = put("te_grid")
+    put("te_fspl")
+    t.n_ti = put("ti_grid")
+    put("ti_fspl")
+    return t, keep
+
+
 class RaysParams(C.Structure):
     """ctypes image of ``rays_params_t`` (include/rays_hip.h)."""
 
@@ -104,6 +166,7 @@ class RaysParams(C.Structure):
         ("slab", SlabParams), ("solovev", SolovevParams),
         ("damping_model", C.c_int32), ("multi_spec_damping", C.c_int32),
         ("total_damping_limit", C.c_double),
+        ("axisym", AxisymParams),
     ]
 
 
@@ -158,8 +221,12 @@ def _lookup(table: Dict[str, int], name: Any, what: str) -> int:
     return table[key]
 
 
-def params_from_namelist(nml: Dict[str, Dict[str, Any]]) -> RaysParams:
-    """Build ``rays_params_t`` the way `initialize(read_input=.true.)` builds module state."""
+def params_from_namelist(nml: Dict[str, Dict[str, Any]], axisym_tables: Dict[str, Any] = None) -> RaysParams:
+    """Build ``rays_params_t`` the way `initialize(read_input=.true.)` builds module state.
+
+    equilib_model = 'axisym_toroid' needs the host-built spline tables (+ the eqdsk-derived box and
+    psiB scalars) in ``axisym_tables``: coefficient generation is host-side initialisation in RAYS
+    (initialize_eqdsk_magnetics_spline_interp) and is not re-implemented in this Python mirror."""
     p = RaysParams()
     p.abi_version = ABI_VERSION
     diag = nml.get("diagnostics_list", {})
@@ -237,6 +304,26 @@ def params_from_namelist(nml: Dict[str, Dict[str, Any]]) -> RaysParams:
             vals = _arr(s.get(name.lower()), NS0, 0.0)
             for i in range(NS0):
                 getattr(q, name)[i] = float(vals[i])
+    elif p.equilib_model == EQUILIB["axisym_toroid"]:
+        s = nml.get("axisym_toroid_eq_list", {})
+        if axisym_tables is None:
+            raise ConfigError("equilib_model='axisym_toroid' needs axisym_tables (host-built spline tables)")
+        q = p.axisym
+        q.magnetics_model = _lookup(AXI_MAGNETICS, s.get("magnetics_model", ""), "magnetics model")
+        q.density_prof_model = _lookup(AXI_N, s.get("density_prof_model", ""), "density_prof_model")
+        tm = _arr(s.get("temperature_prof_model"), NS0, " ")
+        for i in range(nspec + 1):
+            q.t_prof_model[i] = _lookup(AXI_T, tm[i], "temperature_prof_model")
+        q.plasma_psi_limit = float(s.get("plasma_psi_limit", 1.0))
+        for name in ("alphan1", "alphan2", "d_scrape_off"):
+            setattr(q, name, float(s.get(name, 0.0)))
+        q.T_scrape_off = float(s.get("t_scrape_off", 0.0))
+        for name in ("alphat1", "alphat2"):
+            vals = _arr(s.get(name), NS0, 0.0)
+            for i in range(NS0):
+                getattr(q, name)[i] = float(vals[i])
+        for name in ("box_rmin", "box_rmax", "box_zmin", "box_zmax", "psiB"):
+            setattr(q, name, float(axisym_tables[name]))
     else:
         s = nml.get("solovev_eq_list", {})
         q = p.solovev

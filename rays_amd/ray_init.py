@@ -119,9 +119,91 @@ def _host_fields(p: RaysParams, rvec) -> Tuple[int, np.ndarray, np.ndarray, Dict
     return err, b, ns, extra
 
 
-def _launch_eq(p: RaysParams, rvec):
+# ---- axisym_toroid launch-point fields from the host-built spline tables ------------------------------
+def _spl_cell(x, xget):
+    nx = len(x)
+    z = min(max(xget, x[0]), x[-1])
+    nxm = nx - 1
+    i = int(1 + nxm * (z - x[0]) / (x[-1] - x[0]))
+    i = max(1, min(i, nxm))
+    if z < x[i - 1]:
+        i -= 1
+    elif z > x[i]:
+        i += 1
+    i = max(1, min(i, nxm))
+    return i, z - x[i - 1]
+
+
+def _spl1(grid, fspl, x):
+    i, dx = _spl_cell(grid, x)
+    c = np.asarray(fspl).reshape(-1, 4)[i - 1]
+    return c[0] + dx * (c[1] + dx * (c[2] + dx * c[3]))
+
+
+def _axisym_fields(p: RaysParams, rvec, tab):
+    """B, density and grad(psi) at a launch point (eqdsk_magnetics_spline_interp_m.f90:206-282,
+    bcspevfn f / fx / fy), for axisym_toroid ray initialisation."""
+    from .params import AXI_N
+
+    a = p.axisym
+    x, y, z = (float(t) for t in rvec)
+    n = p.nspec + 1
+    r = math.sqrt(x * x + y * y)
+    tiny = 10.0e-14
+    err = 0
+    if r < a.box_rmin - tiny or r > a.box_rmax + tiny:
+        err = 22
+    if z < a.box_zmin - tiny or z > a.box_zmax + tiny:
+        err = 23
+    if err:
+        return err, np.zeros(3), np.zeros(n), {}
+    i, dx = _spl_cell(tab["r_grid"], r)
+    j, dy = _spl_cell(tab["z_grid"], z)
+    nr = len(tab["r_grid"])
+    F = np.asarray(tab["psi_fspl"]).reshape(-1, 4, 4)[(i - 1) + nr * (j - 1)].T  # F[a-1][b-1] = f(a,b,i,j)
+    psi = F[0][0] + dy * (F[0][1] + dy * (F[0][2] + dy * F[0][3])) + \
+        dx * (F[1][0] + dy * (F[1][1] + dy * (F[1][2] + dy * F[1][3])) +
+              dx * (F[2][0] + dy * (F[2][1] + dy * (F[2][2] + dy * F[2][3])) +
+                    dx * (F[3][0] + dy * (F[3][1] + dy * (F[3][2] + dy * F[3][3])))))
+    psi_r = F[1][0] + dy * (F[1][1] + dy * (F[1][2] + dy * F[1][3])) + \
+        2.0 * dx * (F[2][0] + dy * (F[2][1] + dy * (F[2][2] + dy * F[2][3])) +
+                    1.5 * dx * (F[3][0] + dy * (F[3][1] + dy * (F[3][2] + dy * F[3][3]))))
+    psi_z = F[0][1] + dy * (2.0 * F[0][2] + dy * 3.0 * F[0][3]) + \
+        dx * (F[1][1] + dy * (2.0 * F[1][2] + dy * 3.0 * F[1][3]) +
+              dx * (F[2][1] + dy * (2.0 * F[2][2] + dy * 3.0 * F[2][3]) +
+                    dx * (F[3][1] + dy * (2.0 * F[3][2] + dy * 3.0 * F[3][3]))))
+    rbphi = _spl1(tab["rb_grid"], tab["rb_fspl"], r)
+    br, bz, bphi = psi_z / r, -psi_r / r, rbphi / r
+    gradpsi = np.array([-x * bz, -y * bz, r * br])
+    psiN = psi / a.psiB
+    b = np.array([br * x / r - bphi * y / r, br * y / r + bphi * x / r, bz])
+    if psiN > a.plasma_psi_limit:
+        err = 24
+    ns = np.zeros(n)
+    if a.density_prof_model == AXI_N["constant"]:
+        dens = 1.0
+    elif a.density_prof_model == AXI_N["parabolic"]:
+        dens = 0.0
+        if psiN < 1.0:
+            dens = _pow(1.0 - _pow(psiN, a.alphan2), a.alphan1)
+        dens = max(dens, a.d_scrape_off) if dens < a.d_scrape_off else dens
+    else:
+        dens = _spl1(tab["ne_grid"], tab["ne_fspl"], psiN) if psiN <= 1.0 else 0.0
+        if dens < a.d_scrape_off:
+            dens = a.d_scrape_off
+    for k in range(n):
+        ns[k] = p.n0s[k] if a.density_prof_model == AXI_N["constant"] else p.n0s[k] * dens
+    if ns.min() < 0.0:
+        err = 13
+    return err, b, ns, dict(gradpsi=gradpsi, psiN=psiN)
+
+
+def _launch_eq(p: RaysParams, rvec, tab=None):
     """bunit, alpha(0:nspec), gamma(0:nspec) as `equilibrium` would give (equilibrium_m.f90:238-265)."""
-    err, b, ns, extra = _host_fields(p, rvec)
+    if p.equilib_model == EQUILIB["axisym_toroid"]:
+        err, b, ns, extra = _axisym_fields(p, rvec, tab)
+    else:
+        err, b, ns, extra = _host_fields(p, rvec)
     if err:
         return err, None, None, None, extra
     bmag = math.sqrt((b[0] * b[0] + b[1] * b[1]) + b[2] * b[2])
@@ -289,11 +371,62 @@ def ray_init_solovev_nphi_ntheta(p: RaysParams, nml: Dict[str, Dict[str, Any]]):
     return rvec0, rindex_vec0, ray_pwr_wt
 
 
-def initialize_ray_init(p: RaysParams, nml: Dict[str, Dict[str, Any]]):
+def ray_init_axisym_toroid_R_Z_nphi_ntheta(p: RaysParams, nml: Dict[str, Dict[str, Any]], tab):
+    """axisym_toroid_ray_init_R_Z_nphi_ntheta_m.f90:67-244 (same construction as the Solovev fan,
+    launch point given directly as R, Z; the launch position is NOT stepped: :143-147)."""
+    g = nml.get("axisym_toroid_ray_init_r_z_nphi_ntheta_list", {})
+    rf = nml.get("rf_list", {})
+    nray_max = int(nml.get("ray_init_list", {}).get("nray_max", 0))
+    gi = lambda k, d=1: int(g.get(k, d))
+    gf = lambda k, d=0.0: float(g.get(k, d))
+    n_R, n_Z = gi("n_r_launch"), gi("n_z_launch")
+    n_nt, n_np = gi("n_rindex_theta"), gi("n_rindex_phi")
+    nray = n_R * n_Z * n_nt * n_np
+    if not (0 < nray <= nray_max):
+        raise ConfigError(f"axisym_toroid ray init: improper number of rays  nray={nray}")
+    rv, nv = [], []
+    for _ in range(n_R * n_Z):
+        rvec = np.array([gf("r_launch0"), 0.0, gf("z_launch0")])
+        err, bunit, alpha, gamma, extra = _launch_eq(p, rvec, tab)
+        if err:
+            continue
+        gradpsi = extra["gradpsi"]
+        psi_unit = gradpsi / math.sqrt((gradpsi[0] * gradpsi[0] + gradpsi[1] * gradpsi[1])
+                                       + gradpsi[2] * gradpsi[2])
+        phi_unit = np.array([0.0, 1.0, 0.0])
+        theta_unit = np.array([-gradpsi[2], 0.0, gradpsi[0]])
+        theta_unit = theta_unit / math.sqrt((theta_unit[0] * theta_unit[0] + 0.0) + theta_unit[2] * theta_unit[2])
+        trans_unit = np.array([bunit[1] * psi_unit[2] - bunit[2] * psi_unit[1],
+                               bunit[2] * psi_unit[0] - bunit[0] * psi_unit[2],
+                               bunit[0] * psi_unit[1] - bunit[1] * psi_unit[0]])
+        i_nt = np.arange(n_nt, dtype=np.float64)[:, None]
+        i_np = np.arange(n_np, dtype=np.float64)[None, :]
+        r_th = np.broadcast_to(gf("rindex_theta0") + i_nt * gf("delta_rindex_theta"), (n_nt, n_np))
+        r_ph = np.broadcast_to(gf("rindex_phi0") + i_np * gf("delta_rindex_phi"), (n_nt, n_np))
+        rindex = r_ph[..., None] * phi_unit + r_th[..., None] * theta_unit
+        n3 = (bunit[0] * rindex[..., 0] + bunit[1] * rindex[..., 1]) + bunit[2] * rindex[..., 2]
+        n2 = (trans_unit[0] * rindex[..., 0] + trans_unit[1] * rindex[..., 1]) + trans_unit[2] * rindex[..., 2]
+        npsi = solve_n1_vs_n2_n3(alpha, gamma, str(rf.get("wave_mode", "")), int(rf.get("k0_sign", 1)), n2, n3)
+        keep = ~np.isnan(npsi)
+        rv.append(np.broadcast_to(rvec, (int(keep.sum()), 3)))
+        nv.append(rindex[keep] - npsi[keep][:, None] * psi_unit)
+    if not rv or sum(len(a) for a in rv) == 0:
+        raise ConfigError("No successful ray initializations")
+    rvec0 = np.ascontiguousarray(np.concatenate(rv, axis=0))
+    rindex_vec0 = np.ascontiguousarray(np.concatenate(nv, axis=0))
+    n = len(rvec0)
+    return rvec0, rindex_vec0, np.full(n, 1.0) / n
+
+
+def initialize_ray_init(p: RaysParams, nml: Dict[str, Dict[str, Any]], axisym_tables=None):
     """ray_init_m.f90:72-127 dispatch on ray_init_model."""
     model = str(nml.get("ray_init_list", {}).get("ray_init_model", "")).strip()
     if model == "simple_slab":
         return simple_slab_ray_init(p, nml)
     if model == "solovev":
         return ray_init_solovev_nphi_ntheta(p, nml)
+    if model == "axisym_toroid_ray_init_R_Z_nphi_ntheta":
+        if axisym_tables is None:
+            raise ConfigError("axisym_toroid ray init needs the host-built spline tables")
+        return ray_init_axisym_toroid_R_Z_nphi_ntheta(p, nml, axisym_tables)
     raise ConfigError(f"initialize_ray_init: invalid ray_init_model = {model!r}")

@@ -12,13 +12,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 GOLDEN_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_num",
                 "gold_solovev64_sg_cold", "gold_solovev64_sg_num",
-                "gold_solovev64_damp_rk4", "gold_solovev64_damp_sg"]
+                "gold_solovev64_damp_rk4", "gold_solovev64_damp_sg", "gold_axisym64_eqdsk_damp_rk4"]
 
 
 def load_golden(name):
     g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"), allow_pickle=False)
     nml = read_namelist(os.path.join(ROOT, "configs", str(g["config"])))
-    return g, nml, params_from_namelist(nml)
+    tab = {k[4:]: (float(g[k]) if g[k].ndim == 0 else g[k]) for k in g.files if k.startswith("axi_")}
+    if tab:  # eqdsk equilibrium: hand the host-built spline tables to every implementation under test
+        from rays_amd import hip
+        from tests import emul_lib, oracle_lib
+
+        oracle_lib.set_axisym_tables(tab)
+        emul_lib.set_axisym_tables(tab)
+        hip.set_axisym_tables(tab)
+    return g, nml, params_from_namelist(nml, tab or None)
 
 
 def stop_codes(flags):

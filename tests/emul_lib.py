@@ -8,7 +8,7 @@ import subprocess
 
 import numpy as np
 
-from rays_amd.params import RaysParams
+from rays_amd.params import AxisymTables, RaysParams, axisym_tables_struct
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _DIR = os.path.join(_ROOT, "tests", "hip_emul")
@@ -49,6 +49,14 @@ def lib():
         _lib.rays_emul_set_zfun_table.argtypes = [dp, C.c_int, C.c_double, C.c_double]
         _set_zfun(_lib.rays_emul_set_zfun_table)
     return _lib
+
+
+def set_axisym_tables(tab: dict):
+    t, keep = axisym_tables_struct(tab)
+    fn = lib().rays_emul_set_axisym_tables
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(AxisymTables)]
+    fn(C.byref(t))
 
 
 def trace(p: RaysParams, rvec0, rindex_vec0) -> dict:

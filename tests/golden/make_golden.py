@@ -19,7 +19,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from tests.refdump import read_dump  # noqa: E402
+from tests.refdump import read_axisym_tables, read_dump  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref", "rays_ref_dump")
 
@@ -33,6 +33,10 @@ CASES = [
     # fundamental-ECH damping (damp_fund_ECH, nv = 8): constant density + parabolic Te, B0 = 3.3 T
     ("gold_solovev64_damp_rk4", "gold_solovev64_damp_rk4.in", list(range(0, 64, 5)), 0, 0),
     ("gold_solovev64_damp_sg", "gold_solovev64_damp_sg.in", list(range(0, 64, 5)), 0, 0),
+    # axisym_toroid: eqdsk bicubic-spline magnetics (configs/solovev_65x65.geqdsk, written by
+    # tools/make_solovev_eqdsk.py) + splined density + parabolic Te + ECH damping; the fixture also
+    # carries the host-built spline tables (RAYS_DUMP_AXISYM)
+    ("gold_axisym64_eqdsk_damp_rk4", "gold_axisym64_eqdsk_damp_rk4.in", list(range(0, 64, 5)), 10, 120),
 ]
 
 
@@ -42,9 +46,15 @@ def main():
     for name, cfg, subset, stride, nprobe in CASES:
         with tempfile.TemporaryDirectory() as d:
             shutil.copy(os.path.join(ROOT, "configs", cfg), os.path.join(d, "rays.in"))
-            env = dict(os.environ, RAYS_DUMP_FILE="dump.bin", RAYS_DUMP_PROBE=str(stride))
+            for f in os.listdir(os.path.join(ROOT, "configs")):
+                if f.endswith(".geqdsk"):
+                    shutil.copy(os.path.join(ROOT, "configs", f), d)
+            env = dict(os.environ, RAYS_DUMP_FILE="dump.bin", RAYS_DUMP_PROBE=str(stride),
+                       RAYS_DUMP_AXISYM="axisym.bin")
             subprocess.run([REF], cwd=d, env=env, check=True, stdout=subprocess.DEVNULL)
             ref = read_dump(os.path.join(d, "dump.bin"))
+            axi = read_axisym_tables(os.path.join(d, "axisym.bin")) \
+                if os.path.exists(os.path.join(d, "axisym.bin")) else None
         idx = np.arange(ref["nray"]) if subset is None else np.array(subset)
         npts = ref["npoints"][idx]
         keep = int(npts.max())
@@ -64,6 +74,9 @@ def main():
         # beyond npoints the reference arrays are zero (ray_results_m.f90:154-164)
         for r, n in enumerate(npts):
             assert not ref["ray_vec"][idx[r], n:, :].any() and not ref["residual"][idx[r], n:].any()
+        if axi is not None:
+            for k, v in axi.items():
+                out["axi_" + k] = np.asarray(v)
         if stride and "probes" in ref:
             pr = ref["probes"]
             sel = np.linspace(0, len(pr) - 1, min(nprobe, len(pr))).astype(int)

@@ -30,6 +30,19 @@ extern "C" int rays_emul_set_zfun_table(const double* f, int nx, double x_min, d
   return 0;
 }
 
+static std::vector<double> g_axi[11];
+static int g_axi_n[6];
+extern "C" int rays_emul_set_axisym_tables(const rays_axisym_tables_t* t) {
+  const double* src[11] = {t->r_grid, t->z_grid, t->psi_fspl, t->rb_grid, t->rb_fspl, t->ne_grid, t->ne_fspl,
+                           t->te_grid, t->te_fspl, t->ti_grid, t->ti_fspl};
+  const size_t len[11] = {(size_t)t->nr, (size_t)t->nz, (size_t)16 * t->nr * t->nz, (size_t)t->n_rb, (size_t)4 * t->n_rb,
+                          (size_t)t->n_ne, (size_t)4 * t->n_ne, (size_t)t->n_te, (size_t)4 * t->n_te,
+                          (size_t)t->n_ti, (size_t)4 * t->n_ti};
+  for (int k = 0; k < 11; k++) g_axi[k].assign(src[k] ? src[k] : nullptr, src[k] ? src[k] + len[k] : nullptr);
+  g_axi_n[0] = t->nr; g_axi_n[1] = t->nz; g_axi_n[2] = t->n_rb; g_axi_n[3] = t->n_ne; g_axi_n[4] = t->n_te; g_axi_n[5] = t->n_ti;
+  return 0;
+}
+
 extern "C" int rays_emul_trace(const rays_params_t* p, int nray, const double* rvec0,
                                const double* rindex_vec0, double* ray_vec, double* residual,
                                int32_t* npoints, int32_t* stop_code, double* end_ray_vec,
@@ -45,10 +58,19 @@ extern "C" int rays_emul_trace(const rays_params_t* p, int nray, const double* r
     if (g_zfun.empty()) return 2;
     D.zf_fspl = g_zfun.data(); D.zf_nx = g_zf_nx; D.zf_xmin = g_zf_xmin; D.zf_xmax = g_zf_xmax;
   }
+  if (p->equilib_model == RAYS_EQ_AXISYM) {
+    if (g_axi[2].empty()) return 3;
+    D.a_nr = g_axi_n[0]; D.a_nz = g_axi_n[1]; D.a_n_rb = g_axi_n[2]; D.a_n_ne = g_axi_n[3]; D.a_n_te = g_axi_n[4]; D.a_n_ti = g_axi_n[5];
+    D.a_r_grid = g_axi[0].data(); D.a_z_grid = g_axi[1].data(); D.a_psi_fspl = g_axi[2].data();
+    D.a_rb_grid = g_axi[3].data(); D.a_rb_fspl = g_axi[4].data(); D.a_ne_grid = g_axi[5].data(); D.a_ne_fspl = g_axi[6].data();
+    D.a_te_grid = g_axi[7].data(); D.a_te_fspl = g_axi[8].data(); D.a_ti_grid = g_axi[9].data(); D.a_ti_fspl = g_axi[10].data();
+  }
   const int e = p->equilib_model, d = p->ray_deriv, s = p->ode_solver;
   if (e == 0 && d == 0) run<0, 0>(s, p->nv, D, A);
   else if (e == 0 && d == 1) run<0, 1>(s, p->nv, D, A);
   else if (e == 1 && d == 0) run<1, 0>(s, p->nv, D, A);
-  else run<1, 1>(s, p->nv, D, A);
+  else if (e == 1 && d == 1) run<1, 1>(s, p->nv, D, A);
+  else if (e == 2 && d == 0) run<2, 0>(s, p->nv, D, A);
+  else run<2, 1>(s, p->nv, D, A);
   return 0;
 }

@@ -7,7 +7,7 @@ import subprocess
 
 import numpy as np
 
-from rays_amd.params import RaysParams
+from rays_amd.params import AxisymTables, RaysParams, axisym_tables_struct
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _LIB = os.path.join(_ROOT, "oracle", "librays_oracle.so")
@@ -41,6 +41,8 @@ def lib():
         _lib.rays_oracle_set_zfun_table.restype = C.c_int
         _lib.rays_oracle_set_zfun_table.argtypes = [dp, C.c_int, C.c_double, C.c_double]
         _set_zfun(_lib.rays_oracle_set_zfun_table)
+        _lib.rays_oracle_set_axisym_tables.restype = C.c_int
+        _lib.rays_oracle_set_axisym_tables.argtypes = [C.POINTER(AxisymTables)]
         _lib.rays_oracle_check_params.restype = C.c_int
         _lib.rays_oracle_check_params.argtypes = [C.POINTER(RaysParams)]
     return _lib
@@ -52,6 +54,11 @@ def _dp(a):
 
 def _ip(a):
     return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def set_axisym_tables(tab: dict):
+    t, keep = axisym_tables_struct(tab)
+    lib().rays_oracle_set_axisym_tables(C.byref(t))
 
 
 def trace(p: RaysParams, rvec0, rindex_vec0, nthreads: int = 0) -> dict:

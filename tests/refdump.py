@@ -48,3 +48,29 @@ def read_dump(path: str) -> dict:
         off += rec.itemsize * nprobe
     assert off == len(b), (off, len(b))
     return out
+
+
+def read_axisym_tables(path: str) -> dict:
+    """Spline tables written by ref_dump_driver.f90 (RAYS_DUMP_AXISYM)."""
+    b = open(path, "rb").read()
+    nr, nz, n_rb, n_ne, n_te, n_ti = (int(x) for x in np.frombuffer(b, dtype="<i4", count=6))
+    off = 24
+    sc = np.frombuffer(b, dtype="<f8", count=6, offset=off)
+    off += 48
+    out = dict(zip(("box_rmin", "box_rmax", "box_zmin", "box_zmax", "plasma_psi_limit", "psiB"),
+                   (float(x) for x in sc)))
+
+    def take(n):
+        nonlocal off
+        a = np.frombuffer(b, dtype="<f8", count=n, offset=off).copy()
+        off += 8 * n
+        return a
+
+    out["r_grid"], out["z_grid"] = take(nr), take(nz)
+    out["psi_fspl"] = take(16 * nr * nz)          # fspl(4,4,nr,nz) Fortran order
+    out["rb_grid"], out["rb_fspl"] = take(n_rb), take(4 * n_rb)
+    for key, n in (("ne", n_ne), ("te", n_te), ("ti", n_ti)):
+        if n:
+            out[key + "_grid"], out[key + "_fspl"] = take(n), take(4 * n)
+    assert off == len(b), (off, len(b))
+    return out

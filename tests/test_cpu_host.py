@@ -35,13 +35,16 @@ def test_module_state_equals_reference(name):
         np.testing.assert_array_equal(np.array(getattr(p, key)[:]), g[key])
     if p.equilib_model == 1:
         assert p.solovev.psiB == float(g["psiB"])
+    if p.equilib_model == 2:
+        assert p.nv == 8 and p.axisym.psiB == float(g["axi_psiB"])
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 def test_ray_init_equals_reference(name):
     """simple_slab / solovev n_theta x n_phi launchers: same rays, same order, same bits."""
     g, nml, p = load_golden(name)
-    r0, n0, _ = initialize_ray_init(p, nml)
+    tab = {k[4:]: (float(g[k]) if g[k].ndim == 0 else g[k]) for k in g.files if k.startswith("axi_")}
+    r0, n0, _ = initialize_ray_init(p, nml, tab or None)
     assert len(r0) == int(g["nray_full"])
     np.testing.assert_array_equal(r0, g["rvec0_full"])
     np.testing.assert_array_equal(n0, g["rindex_vec0_full"])

@@ -22,6 +22,9 @@ HIPBIN = os.path.join(ROOT, "oracle", "_ref", "rays_hip_dropin")
 def _run(binary, cfg, d):
     os.makedirs(d, exist_ok=True)
     shutil.copy(os.path.join(ROOT, "configs", cfg), os.path.join(d, "rays.in"))
+    for f in os.listdir(os.path.join(ROOT, "configs")):
+        if f.endswith(".geqdsk"):
+            shutil.copy(os.path.join(ROOT, "configs", f), d)
     env = dict(os.environ, RAYS_DUMP_FILE="dump.bin", RAYS_DUMP_PROBE="0")
     subprocess.run([binary], cwd=d, env=env, check=True, stdout=subprocess.DEVNULL, timeout=600)
     return read_dump(os.path.join(d, "dump.bin"))
@@ -31,7 +34,7 @@ def _run(binary, cfg, d):
                     reason="reference binaries not built (oracle/build_ref.sh needs /root/reference)")
 @pytest.mark.parametrize("cfg", ["cfg1_slab16_rk4.in", "cfg2_solovev1024_rk4.in",
                                  "gold_solovev64_sg_cold.in", "gold_solovev64_rk4_num.in",
-                                 "gold_solovev64_damp_rk4.in"])
+                                 "gold_solovev64_damp_rk4.in", "gold_axisym64_eqdsk_damp_rk4.in"])
 def test_fortran_dropin_equals_reference_binary(cfg):
     with tempfile.TemporaryDirectory() as d:
         ref = _run(REF, cfg, os.path.join(d, "ref"))
