@@ -63,9 +63,12 @@ def test_sg_full_fan_matches_oracle(name):
 def test_device_functions_match_reference_probes(name):
     g, nml, p = load_golden(name)
     pr = g["probes"]
-    dev = hip.probe(p, pr["v"][:, :7])
+    from rays_amd.params import copy_params
+    q = copy_params(p)          # the probe kernel evaluates the nv = 7 rows
+    q.nv, q.damping_model = 7, 0
+    dev = hip.probe(q, pr["v"][:, :7])
     for key in ("cold", "num", "dvds"):
-        ref = pr[key]
+        ref = pr[key][:, :7]
         err = np.abs(dev[key] - ref) / np.maximum(np.abs(ref), 1e-300)
         err = np.where(np.isnan(ref) & np.isnan(dev[key]), 0.0, err)
         assert np.nanmax(err) < 1e-9 if key == "num" else np.nanmax(err) < 1e-12, (key, np.nanmax(err))
