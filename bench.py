@@ -45,8 +45,9 @@ def build_fan(cfg_path, world, fan_scale=1, nstep_max=None):
     if nstep_max is not None:
         nml["ode_list"]["nstep_max"] = int(nstep_max)
     if world > 1:  # weak scaling: world x more launch angles in n_theta over the same range
-        g = nml["solovev_ray_init_nphi_ktheta_list"] if "solovev_ray_init_nphi_ktheta_list" in nml \
-            else nml["simple_slab_ray_init_list"]
+        g = next(nml[k] for k in ("solovev_ray_init_nphi_ktheta_list",
+                                   "axisym_toroid_ray_init_r_z_nphi_ntheta_list",
+                                   "simple_slab_ray_init_list") if k in nml)
         if "n_rindex_theta" in g:
             g["n_rindex_theta"] = int(g["n_rindex_theta"]) * world
             g["delta_rindex_theta"] = float(g["delta_rindex_theta"]) / world
@@ -54,8 +55,15 @@ def build_fan(cfg_path, world, fan_scale=1, nstep_max=None):
             g["n_ky_launch"] = int(g["n_ky_launch"]) * world
             g["delta_rindex_y0"] = float(g.get("delta_rindex_y0", 0.0)) / world
         nml["ray_init_list"]["nray_max"] = int(nml["ray_init_list"]["nray_max"]) * world
-    p = params_from_namelist(nml)
-    r0, n0, _ = initialize_ray_init(p, nml)
+    from rays_amd.trace import load_axisym_tables
+
+    tab = load_axisym_tables(cfg_path, nml)
+    p = params_from_namelist(nml, tab)
+    if tab is not None:
+        from rays_amd import hip
+
+        hip.set_axisym_tables(tab)
+    r0, n0, _ = initialize_ray_init(p, nml, tab)
     return nml, p, r0, n0
 
 

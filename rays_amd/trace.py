@@ -51,6 +51,21 @@ class RayResults:
         return int(np.maximum(self.npoints.astype(np.int64) - 1, 0).sum())
 
 
+def load_axisym_tables(namelist_path: str, nml: Dict[str, Dict[str, Any]]) -> Optional[Dict[str, Any]]:
+    """Host-built spline tables of an eqdsk equilibrium: `<eqdsk_file_name>.tables.npz` next to the
+    namelist (None for the analytic equilibria)."""
+    import os
+
+    if str(nml.get("equilibrium_list", {}).get("equilib_model", "")).strip() != "axisym_toroid":
+        return None
+    eq = str(nml.get("eqdsk_magnetics_spline_interp_list", {}).get("eqdsk_file_name", "")).strip()
+    f = os.path.join(os.path.dirname(os.path.abspath(namelist_path)), eq + ".tables.npz")
+    if not os.path.exists(f):
+        raise FileNotFoundError(f"{f}: spline tables of the eqdsk equilibrium (built by the RAYS host)")
+    z = np.load(f)
+    return {k: (float(z[k]) if z[k].ndim == 0 else z[k]) for k in z.files}
+
+
 class RaysRun:
     """Module state after `initialize`: parameters + launched fan."""
 
@@ -64,10 +79,16 @@ class RaysRun:
         hip.check_params(params)
 
     @classmethod
-    def from_namelist(cls, path: str) -> "RaysRun":
+    def from_namelist(cls, path: str, axisym_tables: Optional[Dict[str, Any]] = None) -> "RaysRun":
+        """`initialize(read_input=.true.)`.  For equilib_model = 'axisym_toroid' the host-built spline
+        tables are taken from `axisym_tables` or from `<eqdsk_file_name>.tables.npz` next to the
+        namelist (written by a RAYS host, see tests/golden/make_golden.py)."""
         nml = read_namelist(path)
-        p = params_from_namelist(nml)
-        r0, n0, w = initialize_ray_init(p, nml)
+        tab = axisym_tables if axisym_tables is not None else load_axisym_tables(path, nml)
+        p = params_from_namelist(nml, tab)
+        if tab is not None:
+            hip.set_axisym_tables(tab)
+        r0, n0, w = initialize_ray_init(p, nml, tab)
         return cls(p, r0, n0, w, nml)
 
     @property

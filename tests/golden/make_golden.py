@@ -77,6 +77,9 @@ def main():
         if axi is not None:
             for k, v in axi.items():
                 out["axi_" + k] = np.asarray(v)
+            # the same tables next to the eqdsk file, for the Python host (RaysRun.from_namelist)
+            np.savez_compressed(os.path.join(ROOT, "configs", "solovev_65x65.geqdsk.tables.npz"),
+                                **{k: np.asarray(v) for k, v in axi.items()})
         if stride and "probes" in ref:
             pr = ref["probes"]
             sel = np.linspace(0, len(pr) - 1, min(nprobe, len(pr))).astype(int)
