@@ -860,6 +860,19 @@ static inline double zf_x(int i) { /* x_grid(i), 1-based (zfunctions_m.f90:444) 
   return zf_xmin + (double)(i - 1) * (zf_xmax - zf_xmin) / (double)(zf_nx - 1);
 }
 
+/* real**integer as flang lowers it (llvm.powi -> compiler-rt __powidf2: square and multiply) */
+static double powi_rt(double a, int b) {
+  const int recip = b < 0;
+  double r = 1.;
+  for (;;) {
+    if (b & 1) r = r * a;
+    b /= 2;
+    if (b == 0) break;
+    a = a * a;
+  }
+  return recip ? 1. / r : r;
+}
+
 static cplx zfun_real_arg_spline(double z) {
   const double spline_range = 10.0;
   double re;
@@ -878,7 +891,7 @@ static cplx zfun_real_arg_spline(double z) {
     static const double A[6] = {1., 1. / 2., 3. / 4., 15. / 8., 105. / 16., 945. / 32.};
     const double z_inv = 1.0 / z;
     re = 0.;
-    for (int i = 1; i <= 6; i++) re = re - pow(z_inv, 2 * i - 1) * A[i - 1];
+    for (int i = 1; i <= 6; i++) re = re - powi_rt(z_inv, 2 * i - 1) * A[i - 1];
   }
   const double sqrt_pi = sqrt(3.14159265358979323846);
   return c_make(re, sqrt_pi * exp(-(z * z)));

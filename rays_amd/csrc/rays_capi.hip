@@ -18,17 +18,19 @@
 #include "rays_launch.hpp"
 
 namespace rays {
-#define RAYS_DECL_ENTRIES(s, e, d) const KernelEntry* rays_entries_##s##_##e##_##d(int* n);
+#define RAYS_DECL_ENTRIES(s, e, d) \
+  const KernelEntry* rays_entries_##s##_##e##_##d##_0(int* n); \
+  const KernelEntry* rays_entries_##s##_##e##_##d##_1(int* n);
 RAYS_DECL_ENTRIES(0, 0, 0)
 RAYS_DECL_ENTRIES(0, 0, 1)
 RAYS_DECL_ENTRIES(0, 1, 0)
 RAYS_DECL_ENTRIES(0, 1, 1)
+RAYS_DECL_ENTRIES(0, 2, 0)
+RAYS_DECL_ENTRIES(0, 2, 1)
 RAYS_DECL_ENTRIES(1, 0, 0)
 RAYS_DECL_ENTRIES(1, 0, 1)
 RAYS_DECL_ENTRIES(1, 1, 0)
 RAYS_DECL_ENTRIES(1, 1, 1)
-RAYS_DECL_ENTRIES(0, 2, 0)
-RAYS_DECL_ENTRIES(0, 2, 1)
 RAYS_DECL_ENTRIES(1, 2, 0)
 RAYS_DECL_ENTRIES(1, 2, 1)
 hipError_t launch_pack(bool pack, int nray, int nv, int nstep_max, const int32_t* npoints,
@@ -94,11 +96,13 @@ const FlagText kFlags[] = {
 const rays::KernelEntry* find_kernel(const rays_params_t& p) {
   using namespace rays;
   typedef const KernelEntry* (*Getter)(int*);
-  static const Getter getters[2][3][2] = {
-      {{rays_entries_0_0_0, rays_entries_0_0_1}, {rays_entries_0_1_0, rays_entries_0_1_1}, {rays_entries_0_2_0, rays_entries_0_2_1}},
-      {{rays_entries_1_0_0, rays_entries_1_0_1}, {rays_entries_1_1_0, rays_entries_1_1_1}, {rays_entries_1_2_0, rays_entries_1_2_1}}};
+#define RAYS_G(s, e, d) {rays_entries_##s##_##e##_##d##_0, rays_entries_##s##_##e##_##d##_1}
+  static const Getter getters[2][3][2][2] = {
+      {{RAYS_G(0, 0, 0), RAYS_G(0, 0, 1)}, {RAYS_G(0, 1, 0), RAYS_G(0, 1, 1)}, {RAYS_G(0, 2, 0), RAYS_G(0, 2, 1)}},
+      {{RAYS_G(1, 0, 0), RAYS_G(1, 0, 1)}, {RAYS_G(1, 1, 0), RAYS_G(1, 1, 1)}, {RAYS_G(1, 2, 0), RAYS_G(1, 2, 1)}}};
+#undef RAYS_G
   int n = 0;
-  const KernelEntry* e = getters[p.ode_solver][p.equilib_model][p.ray_deriv](&n);
+  const KernelEntry* e = getters[p.ode_solver][p.equilib_model][p.ray_deriv][unit_exponents(p) ? 1 : 0](&n);
   for (int i = 0; i < n; i++)
     if (e[i].ns == p.nspec + 1 && e[i].nv == p.nv) return &e[i];
   return nullptr;

@@ -78,9 +78,21 @@ struct DevParams {
 RAYS_DEV double sq(double x) { return x * x; }
 RAYS_DEV double pow4(double x) { return ((x * x) * x) * x; }  // flang lowers x**4 sequentially
 
-// pow with the exact IEEE identities short-circuited (wave-uniform on the exponent): the BASELINE
-// profiles use exponents 1 and 0 (alphan1 = alphan2 = 1), for which pow is exact by definition.
+// Profile exponents.  The reference evaluates x**alpha with real alpha through libm pow().  pow(x,1)
+// = x and pow(x,0) = 1 are exact by definition, and profiles with unit exponents
+// (alphan1 = alphan2 = 1, the BASELINE fans) are the common case, so the kernels come in two
+// flavours selected on the host (rays_capi.hip: unit_exponents()):
+//   UE = true  : every profile exponent in use is exactly 1 -> pow_u<true, Y1> is x (Y1: the call
+//                site's exponent is alpha) or 1 (the call site's exponent is alpha - 1); no pow code.
+//   UE = false : general exponents, ocml pow (agrees with glibc's to an ulp).
+// Keeping ocml's pow (~400 instructions, inlined at eight call sites) out of the unit-exponent
+// kernels is worth 15 % on the 64k fan although the code is never executed there: it pushes the
+// kernel past 256 VGPRs and adds SGPR spills in the hot loop.
+// The template argument EQ of the kernels carries the flag: EQ = model | (UE ? kEqUnitExp : 0).
+constexpr int kEqUnitExp = 4;
+template <bool UE, bool Y1>
 RAYS_DEV double pow_u(double x, double y) {
+  if (UE) return Y1 ? x : 1.0;
   if (y == 1.0) return x;
   if (y == 0.0) return 1.0;
   return pow(x, y);
@@ -156,13 +168,14 @@ struct EqPoint {
 };
 
 // parabolic_prof            slab_eq_m.f90:354-381  (fp := 0 where the reference leaves it undefined)
+template <bool UE>
 RAYS_DEV void parabolic_prof(double rho, double f_min, double a1, double a2, double& f, double& fp) {
   f = 0.0;
   fp = 0.0;
   if (rho < 1.0) {
-    double pr = pow_u(rho, a2);
-    f = pow_u(1. - pr, a1);
-    fp = -a1 * a2 * pow_u(rho, a2 - 1.) * pow_u(1. - pr, a1 - 1.);
+    double pr = pow_u<UE, true>(rho, a2);
+    f = pow_u<UE, true>(1. - pr, a1);
+    fp = -a1 * a2 * pow_u<UE, false>(rho, a2 - 1.) * pow_u<UE, false>(1. - pr, a1 - 1.);
   }
   if (f < f_min) {
     f = f_min;
@@ -171,7 +184,7 @@ RAYS_DEV void parabolic_prof(double rho, double f_min, double a1, double a2, dou
 }
 
 // slab_eq                   slab_eq_m.f90:125-309
-template <int NS>
+template <int NS, bool UE>
 RAYS_DEV int slab_fields(const DevParams& P, const double rvec[3], double bvec[3], double gbt[3][3],
                          double ns[NS], double gradns[NS][3], double ts[NS], double gradts[NS][3],
                          bool check_box) {
@@ -234,7 +247,7 @@ RAYS_DEV int slab_fields(const DevParams& P, const double rvec[3], double bvec[3
     }
   } else if (P.n_model == RAYS_SLAB_N_PARABOLIC) {
     double f, fp;
-    parabolic_prof(x, P.n_min, P.s_an1, P.s_an2, f, fp);
+    parabolic_prof<UE>(x, P.n_min, P.s_an1, P.s_an2, f, fp);
 #pragma unroll
     for (int is = 0; is < NS; is++) {
       ns[is] = P.n0s[is] * f;
@@ -262,7 +275,7 @@ RAYS_DEV int slab_fields(const DevParams& P, const double rvec[3], double bvec[3
       gradts[is][0] = P.t0s[is] * P.dtdx;
     } else if (m == RAYS_SLAB_T_PARABOLIC) {
       double f, fp;
-      parabolic_prof(x - P.x0, P.T_min[is], P.s_at1[is], P.s_at2[is], f, fp);
+      parabolic_prof<UE>(x - P.x0, P.T_min[is], P.s_at1[is], P.s_at2[is], f, fp);
       ts[is] = P.t0s[is] * f;
       gradts[is][0] = P.t0s[is] * fp;
     }
@@ -281,7 +294,7 @@ RAYS_DEV int slab_fields(const DevParams& P, const double rvec[3], double bvec[3
 }
 
 // solovev_eq + solovev_psi  solovev_eq_m.f90:122-276, 280-322
-template <int NS>
+template <int NS, bool UE>
 RAYS_DEV int solovev_fields(const DevParams& P, const double rvec[3], double bvec[3],
                             double gbt[3][3], double ns[NS], double gradns[NS][3], double ts[NS],
                             double gradts[NS][3], bool check_box) {
@@ -338,9 +351,9 @@ RAYS_DEV int solovev_fields(const DevParams& P, const double rvec[3], double bve
     for (int is = 0; is < NS; is++) ns[is] = P.n0s[is];
   } else if (psiN < 1.0) {  // :214-225
     const double a1 = P.v_an1, a2 = P.v_an2;
-    const double pr = pow_u(psiN, a2);
-    const double prof = pow_u(1. - pr, a1);
-    const double dd_psi = -a1 * a2 * pow_u(psiN, a2 - 1.) * pow_u(1. - pr, a1 - 1.);
+    const double pr = pow_u<UE, true>(psiN, a2);
+    const double prof = pow_u<UE, true>(1. - pr, a1);
+    const double dd_psi = -a1 * a2 * pow_u<UE, false>(psiN, a2 - 1.) * pow_u<UE, false>(1. - pr, a1 - 1.);
 #pragma unroll
     for (int is = 0; is < NS; is++) {
       ns[is] = P.n0s[is] * prof;
@@ -362,9 +375,9 @@ RAYS_DEV int solovev_fields(const DevParams& P, const double rvec[3], double bve
       }
       if (psiN < 1.) {
         const double a1 = P.v_at1[is], a2 = P.v_at2[is];
-        const double pf = pow_u(1. - pow_u(psiN, a2), a1);
+        const double pf = pow_u<UE, true>(1. - pow_u<UE, true>(psiN, a2), a1);
         ts[is] = P.t0s[is] * pf;
-        const double dd_psi = -a1 * a2 * pow_u(psiN, a2 - 1.) * pf;
+        const double dd_psi = -a1 * a2 * pow_u<UE, false>(psiN, a2 - 1.) * pf;
         const double c = P.t0s[is] * dd_psi;
         gradts[is][0] = c * gradpsiN[0];
         gradts[is][1] = c * gradpsiN[1];
@@ -453,7 +466,7 @@ RAYS_DEV void spl2_fpp(const DevParams& P, double x, double y, double out[6]) {
 // axisym_toroid_eq + eqdsk_magnetics_spline_interp
 //   axisym_toroid_eq_m.f90:215-362, eqdsk_magnetics_spline_interp_m.f90:206-282,
 //   density_spline_interp_m.f90:109-130, temperature_spline_interp_m.f90
-template <int NS>
+template <int NS, bool UE>
 RAYS_DEV int axisym_fields(const DevParams& P, const double rvec[3], double bvec[3], double gbt[3][3],
                            double ns[NS], double gradns[NS][3], double ts[NS], double gradts[NS][3],
                            bool check_box) {
@@ -505,7 +518,7 @@ RAYS_DEV int axisym_fields(const DevParams& P, const double rvec[3], double bvec
   } else {
     double dens = 0., dd_psi = 0.;
     if (P.a_n_model == RAYS_AXI_N_PARABOLIC) {
-      parabolic_prof(psiN, P.a_d_scrape, P.a_an1, P.a_an2, dens, dd_psi);
+      parabolic_prof<UE>(psiN, P.a_d_scrape, P.a_an1, P.a_an2, dens, dd_psi);
     } else {
       if (psiN <= 1.0) spl1_fp(P.a_ne_grid, P.a_ne_fspl, P.a_n_ne, psiN, dens, dd_psi);
       if (dens < P.a_d_scrape) {
@@ -536,7 +549,7 @@ RAYS_DEV int axisym_fields(const DevParams& P, const double rvec[3], double bvec
       for (int j = 0; j < NS; j++) gradts[j][0] = gradts[j][1] = gradts[j][2] = 0.;  // `gradts = 0.` (:328)
     } else if (m == RAYS_AXI_T_PARABOLIC) {
       double t_prof, dt_dpsi;
-      parabolic_prof(psiN, P.a_T_scrape, P.a_at1[is], P.a_at2[is], t_prof, dt_dpsi);
+      parabolic_prof<UE>(psiN, P.a_T_scrape, P.a_at1[is], P.a_at2[is], t_prof, dt_dpsi);
       ts[is] = P.t0s[is] * t_prof;
       const double c = P.t0s[is] * dt_dpsi;
       gradts[is][0] = c * gpN[0];
@@ -580,12 +593,14 @@ RAYS_DEV void equilibrium(const DevParams& P, const Recip& Romgrf, const Recip& 
                           const double rvec[3], EqPoint<NS>& eq, bool check_box) {
   double ns[NS], gradns[NS][3], ts[NS], gradts[NS][3];
   int err;
-  if (EQ == RAYS_EQ_SLAB)
-    err = slab_fields<NS>(P, rvec, eq.bvec, eq.gbt, ns, gradns, ts, gradts, check_box);
-  else if (EQ == RAYS_EQ_SOLOVEV)
-    err = solovev_fields<NS>(P, rvec, eq.bvec, eq.gbt, ns, gradns, ts, gradts, check_box);
+  constexpr int MODEL = EQ & 3;
+  constexpr bool UE = (EQ & kEqUnitExp) != 0;
+  if (MODEL == RAYS_EQ_SLAB)
+    err = slab_fields<NS, UE>(P, rvec, eq.bvec, eq.gbt, ns, gradns, ts, gradts, check_box);
+  else if (MODEL == RAYS_EQ_SOLOVEV)
+    err = solovev_fields<NS, UE>(P, rvec, eq.bvec, eq.gbt, ns, gradns, ts, gradts, check_box);
   else
-    err = axisym_fields<NS>(P, rvec, eq.bvec, eq.gbt, ns, gradns, ts, gradts, check_box);
+    err = axisym_fields<NS, UE>(P, rvec, eq.bvec, eq.gbt, ns, gradns, ts, gradts, check_box);
   eq.err = err;
   // When err != 0 the reference returns with eq undefined (:198-202).  We still fill it (fields
   // evaluated at the out-of-box point): callers that stop on err never read it, and check_save,
@@ -873,6 +888,19 @@ RAYS_DEV void deriv_num(const DevParams& P, const EqPoint<NS>& eq0, const double
 // D_WARM and DELTA are default COMPLEX (single precision) in the reference (:36): both
 // assignments truncate to float, reproduced here.  Complex quotients follow __divdc3.
 // ---------------------------------------------------------------------------------------------
+// real**integer as flang lowers it (llvm.powi -> compiler-rt __powidf2: square and multiply)
+RAYS_DEV double powi_rt(double a, int b) {
+  const bool recip = b < 0;
+  double r = 1.;
+  while (true) {
+    if (b & 1) r = r * a;
+    b /= 2;
+    if (b == 0) break;
+    a = a * a;
+  }
+  return recip ? 1. / r : r;
+}
+
 struct Cplx {
   double re, im;
 };
@@ -915,7 +943,7 @@ RAYS_DEV Cplx zfun_real_arg_spline(const DevParams& P, double z) {
     const double A[6] = {1., 1. / 2., 3. / 4., 15. / 8., 105. / 16., 945. / 32.};
     const double z_inv = 1.0 / z;
     re = 0.;
-    for (int i = 1; i <= 6; i++) re = re - pow(z_inv, (double)(2 * i - 1)) * A[i - 1];
+    for (int i = 1; i <= 6; i++) re = re - powi_rt(z_inv, 2 * i - 1) * A[i - 1];
   }
   Cplx r;
   r.re = re;

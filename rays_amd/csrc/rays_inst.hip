@@ -1,5 +1,6 @@
-// rays_inst.hip -- kernel instantiations.  Compiled once per (solver, equilibrium, derivative)
-// group:  -DRAYS_INST_SOLVER={0,1} -DRAYS_INST_EQ={0,1,2} -DRAYS_INST_DERIV={0,1}
+// rays_inst.hip -- kernel instantiations.  Compiled once per (solver, equilibrium, derivative,
+// unit-exponent) group:
+//   -DRAYS_INST_SOLVER={0,1} -DRAYS_INST_EQ={0,1,2} -DRAYS_INST_DERIV={0,1} -DRAYS_INST_UE={0,1}
 // Each group instantiates the species counts NS = 1..6 (nspec = 0..5, species_m.f90:25) and
 // nv = 7 | 12 (integrate_eq_gradients) and 8 | 13 (+ damping) (ode_m.f90:160-173).
 #include "rays_launch.hpp"
@@ -9,15 +10,26 @@
 #include "rays_sg.hpp"
 #endif
 
-#define RAYS_CAT_(a, b, c, d) a##_##b##_##c##_##d
-#define RAYS_CAT(a, b, c, d) RAYS_CAT_(a, b, c, d)
+#define RAYS_CAT_(a, b, c, d, e) a##_##b##_##c##_##d##_##e
+#define RAYS_CAT(a, b, c, d, e) RAYS_CAT_(a, b, c, d, e)
+// the kernels' EQ template argument, as a literal (it appears in the kernel names rocprof prints)
+#if !RAYS_INST_UE
+#define RAYS_INST_EQT RAYS_INST_EQ
+#elif RAYS_INST_EQ == 0
+#define RAYS_INST_EQT 4
+#elif RAYS_INST_EQ == 1
+#define RAYS_INST_EQT 5
+#else
+#define RAYS_INST_EQT 6
+#endif
 #define RAYS_STR_(x) #x
 #define RAYS_STR(x) RAYS_STR_(x)
 
 namespace rays {
 
 namespace {
-constexpr int EQ = RAYS_INST_EQ;
+constexpr int EQ = RAYS_INST_EQT;
+static_assert(EQ == (RAYS_INST_EQ | (RAYS_INST_UE ? kEqUnitExp : 0)), "EQ encoding");
 constexpr int DERIV = RAYS_INST_DERIV;
 
 template <int NS, int NV>
@@ -36,18 +48,22 @@ hipError_t launch_one(const DevParams& P, const TraceArgs& A, hipStream_t stream
 #define RAYS_KNAME "sg_trace_kernel"
 #endif
 #define RAYS_ENTRY(NS, NV) \
-  { RAYS_INST_SOLVER, EQ, NS, DERIV, NV, RAYS_KNAME "<" RAYS_STR(RAYS_INST_EQ) ", " #NS ", " RAYS_STR(RAYS_INST_DERIV) ", " #NV ">", &launch_one<NS, NV> }
+  { RAYS_INST_SOLVER, EQ, NS, DERIV, NV, RAYS_KNAME "<" RAYS_STR(RAYS_INST_EQT) ", " #NS ", " RAYS_STR(RAYS_INST_DERIV) ", " #NV ">", &launch_one<NS, NV> }
 
 const KernelEntry kEntries[] = {
+#ifdef RAYS_INST_FAST  // developer builds (make FAST=1): electrons + one ion species only
+    RAYS_ENTRY(2, 7), RAYS_ENTRY(2, 8),
+#else
     RAYS_ENTRY(1, 7), RAYS_ENTRY(2, 7), RAYS_ENTRY(3, 7), RAYS_ENTRY(4, 7), RAYS_ENTRY(5, 7), RAYS_ENTRY(6, 7),
     RAYS_ENTRY(1, 12), RAYS_ENTRY(2, 12), RAYS_ENTRY(3, 12), RAYS_ENTRY(4, 12), RAYS_ENTRY(5, 12), RAYS_ENTRY(6, 12),
     // nv = 8 | 13: + total-absorption row (damping_model = 'damp_fund_ECH', ode_m.f90:162-166)
     RAYS_ENTRY(1, 8), RAYS_ENTRY(2, 8), RAYS_ENTRY(3, 8), RAYS_ENTRY(4, 8), RAYS_ENTRY(5, 8), RAYS_ENTRY(6, 8),
     RAYS_ENTRY(1, 13), RAYS_ENTRY(2, 13), RAYS_ENTRY(3, 13), RAYS_ENTRY(4, 13), RAYS_ENTRY(5, 13), RAYS_ENTRY(6, 13),
+#endif
 };
 }  // namespace
 
-const KernelEntry* RAYS_CAT(rays_entries, RAYS_INST_SOLVER, RAYS_INST_EQ, RAYS_INST_DERIV)(int* n) {
+const KernelEntry* RAYS_CAT(rays_entries, RAYS_INST_SOLVER, RAYS_INST_EQ, RAYS_INST_DERIV, RAYS_INST_UE)(int* n) {
   *n = (int)(sizeof(kEntries) / sizeof(kEntries[0]));
   return kEntries;
 }

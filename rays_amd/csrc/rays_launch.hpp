@@ -16,7 +16,7 @@ namespace rays {
 enum { SOLVER_RK4 = 0, SOLVER_SG = 1 };
 
 struct KernelEntry {
-  int solver, eq, ns, deriv, nv;
+  int solver, eq, ns, deriv, nv;  // eq = equilibrium model | kEqUnitExp (the kernels' EQ argument)
   const char* name;
   // Launches on `stream` with a grid sized for full residency (persistent waves + lane refill).
   hipError_t (*launch)(const DevParams&, const TraceArgs&, hipStream_t stream, int* grid_blocks);
@@ -59,8 +59,5 @@ inline hipError_t launch_persistent(Kernel kernel, size_t lds_bytes, const DevPa
   return hipGetLastError();
 }
 
-// Implemented in rays_inst_*.hip
-const KernelEntry* rk4_entries(int* n);
-const KernelEntry* sg_entries(int* n);
 
 }  // namespace rays

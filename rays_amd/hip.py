@@ -13,7 +13,7 @@ import numpy as np
 from .params import AxisymTables, RaysParams, axisym_tables_struct
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librays_hip.so")
+LIB_PATH = os.environ.get("RAYS_HIP_LIB") or os.path.join(_HERE, "lib", "librays_hip.so")
 
 # every symbol include/rays_hip.h declares
 EXPORTED_SYMBOLS = (

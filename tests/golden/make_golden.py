@@ -30,6 +30,8 @@ CASES = [
     ("gold_solovev64_sg_cold", "gold_solovev64_sg_cold.in", list(range(0, 64, 5)), 0, 0),
     ("gold_solovev64_sg_num", "gold_solovev64_sg_num.in", list(range(0, 64, 5)), 0, 0),
     ("gold_solovev64_rk4_num", "gold_solovev64_rk4_num.in", list(range(0, 64, 5)), 0, 0),
+    # non-unit profile exponents: the general (libm pow) kernels
+    ("gold_solovev64_pow_rk4", "gold_solovev64_pow_rk4.in", list(range(0, 64, 5)), 20, 120),
     # fundamental-ECH damping (damp_fund_ECH, nv = 8): constant density + parabolic Te, B0 = 3.3 T
     ("gold_solovev64_damp_rk4", "gold_solovev64_damp_rk4.in", list(range(0, 64, 5)), 0, 0),
     ("gold_solovev64_damp_sg", "gold_solovev64_damp_sg.in", list(range(0, 64, 5)), 0, 0),
@@ -41,9 +43,12 @@ CASES = [
 
 
 def main():
+    only = set(sys.argv[1:])  # optional: fixture names to (re)generate
     if not os.path.exists(REF):
         sys.exit("oracle/_ref/rays_ref_dump missing: run `bash oracle/build_ref.sh` first")
     for name, cfg, subset, stride, nprobe in CASES:
+        if only and name not in only:
+            continue
         with tempfile.TemporaryDirectory() as d:
             shutil.copy(os.path.join(ROOT, "configs", cfg), os.path.join(d, "rays.in"))
             for f in os.listdir(os.path.join(ROOT, "configs")):

@@ -65,12 +65,13 @@ extern "C" int rays_emul_trace(const rays_params_t* p, int nray, const double* r
     D.a_rb_grid = g_axi[3].data(); D.a_rb_fspl = g_axi[4].data(); D.a_ne_grid = g_axi[5].data(); D.a_ne_fspl = g_axi[6].data();
     D.a_te_grid = g_axi[7].data(); D.a_te_fspl = g_axi[8].data(); D.a_ti_grid = g_axi[9].data(); D.a_ti_fspl = g_axi[10].data();
   }
-  const int e = p->equilib_model, d = p->ray_deriv, s = p->ode_solver;
-  if (e == 0 && d == 0) run<0, 0>(s, p->nv, D, A);
-  else if (e == 0 && d == 1) run<0, 1>(s, p->nv, D, A);
-  else if (e == 1 && d == 0) run<1, 0>(s, p->nv, D, A);
-  else if (e == 1 && d == 1) run<1, 1>(s, p->nv, D, A);
-  else if (e == 2 && d == 0) run<2, 0>(s, p->nv, D, A);
-  else run<2, 1>(s, p->nv, D, A);
+  // same kernel selection as rays_capi.hip: find_kernel (EQ = model | kEqUnitExp)
+  const int e = p->equilib_model | (unit_exponents(*p) ? rays::kEqUnitExp : 0), d = p->ray_deriv, s = p->ode_solver;
+#define RAYS_EMUL_CASE(E, D) if (e == E && d == D) run<E, D>(s, p->nv, D_, A); else
+  const rays::DevParams& D_ = D;
+  RAYS_EMUL_CASE(0, 0) RAYS_EMUL_CASE(0, 1) RAYS_EMUL_CASE(1, 0) RAYS_EMUL_CASE(1, 1) RAYS_EMUL_CASE(2, 0) RAYS_EMUL_CASE(2, 1)
+  RAYS_EMUL_CASE(4, 0) RAYS_EMUL_CASE(4, 1) RAYS_EMUL_CASE(5, 0) RAYS_EMUL_CASE(5, 1) RAYS_EMUL_CASE(6, 0) RAYS_EMUL_CASE(6, 1)
+  return 4;
+#undef RAYS_EMUL_CASE
   return 0;
 }

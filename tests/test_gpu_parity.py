@@ -9,8 +9,11 @@ from tests.common import GOLDEN_CASES, assert_matches_golden, load_golden
 
 pytestmark = pytest.mark.gpu
 
-RK4_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_num", "gold_solovev64_damp_rk4",
-             "gold_axisym64_eqdsk_damp_rk4"]
+# gold_solovev64_pow_rk4: profile exponents 1.5 / 2 -> the general kernels (ocml pow vs the
+# reference's glibc pow: within the 1e-10 bar, not necessarily bitwise); every other case has unit
+# exponents and runs the unit-exponent kernels
+RK4_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_num", "gold_solovev64_pow_rk4",
+             "gold_solovev64_damp_rk4", "gold_axisym64_eqdsk_damp_rk4"]
 SG_CASES = ["gold_solovev64_sg_cold", "gold_solovev64_sg_num", "gold_solovev64_damp_sg"]
 
 
@@ -59,7 +62,8 @@ def test_sg_full_fan_matches_oracle(name):
         assert (per_ray <= 1e-10).mean() >= 0.9 and per_ray.max() <= 1e-6
 
 
-@pytest.mark.parametrize("name", ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_axisym64_eqdsk_damp_rk4"])
+@pytest.mark.parametrize("name", ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_pow_rk4",
+                                  "gold_axisym64_eqdsk_damp_rk4"])
 def test_device_functions_match_reference_probes(name):
     g, nml, p = load_golden(name)
     pr = g["probes"]
@@ -71,7 +75,10 @@ def test_device_functions_match_reference_probes(name):
         ref = pr[key][:, :7]
         err = np.abs(dev[key] - ref) / np.maximum(np.abs(ref), 1e-300)
         err = np.where(np.isnan(ref) & np.isnan(dev[key]), 0.0, err)
-        assert np.nanmax(err) < 1e-9 if key == "num" else np.nanmax(err) < 1e-12, (key, np.nanmax(err))
+        # finite-difference dD: differences of D at +-0.5e-6 relative offsets amplify an ulp of
+        # libm pow (ocml vs glibc, general-exponent profiles only) by ~1e8
+        tol = (1e-6 if name == "gold_solovev64_pow_rk4" else 1e-9) if key == "num" else 1e-12
+        assert np.nanmax(err) < tol, (key, np.nanmax(err))
         print(name, key, "bitwise" if np.array_equal(dev[key], ref, equal_nan=True) else f"max rel {np.nanmax(err):.2e}")
     both_nan = np.isnan(pr["resid"]) & np.isnan(dev["resid"])
     assert (both_nan | (np.abs(dev["resid"] - pr["resid"]) <= 1e-12)).all()
