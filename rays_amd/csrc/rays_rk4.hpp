@@ -19,7 +19,7 @@ namespace rays {
 
 template <int EQ, int NS, int DERIV, int NV, int K>
 __global__ void __launch_bounds__(256)
-rk4_trace_kernel(const DevParams P, const TraceArgs A) {
+rk4_trace_kernel(const DevParams P, const TraceArgs A_hot) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
@@ -32,7 +32,7 @@ rk4_trace_kernel(const DevParams P, const TraceArgs A) {
 
   // ---- per-lane ray state -------------------------------------------------------------------
   int ray = blockIdx.x * blockDim.x + threadIdx.x;
-  bool alive = ray < A.nray;
+  bool alive = ray < A_hot.nray;
   bool need_init = alive;
   int j = 3;            // stage
   int first = 1;        // stage-3 evaluation is the initial check_save (int, not bool: see rays_sg.hpp)
@@ -45,8 +45,11 @@ rk4_trace_kernel(const DevParams P, const TraceArgs A) {
 #pragma unroll
   for (int i = 0; i < NV; i++) v[i] = w[i] = acc[i] = 0.;
 
+  const Recip R6 = const_recip(6.0, 1.0 / 6.0);  // RN(1/6); div() = the correctly rounded quotient
+
   while (__any(alive)) {
     if (need_init) {  // initialize_ode_vector + per-ray resets (ray_tracing.f90:77-93)
+      const TraceArgs& A = cold_args(A_hot);
       initialize_ode_vector<EQ, NS, NV>(P, A.rvec0 + 3ll * ray, A.rindex_vec0 + 3ll * ray, v);
 #pragma unroll
       for (int i = 0; i < NV; i++) w[i] = v[i];
@@ -93,7 +96,7 @@ rk4_trace_kernel(const DevParams P, const TraceArgs A) {
 #pragma unroll
           for (int i = 0; i < NV; i++) {
             acc[i] = acc[i] + f[i];
-            w[i] = v[i] + dsl * acc[i] / 6.0;  // RK4_ode_m.f90:91
+            w[i] = v[i] + div(dsl * acc[i], R6);  // RK4_ode_m.f90:91  (ds*(...))/6.0
           }
           j = 3;
         }
@@ -105,6 +108,7 @@ rk4_trace_kernel(const DevParams P, const TraceArgs A) {
           stage.put(nbuf, v, 0.);
           nbuf++;
           if (cs_stop) {  // ray did not start: npoints = 1, summary fields stay zero
+            const TraceArgs& A = cold_args(A_hot);
             A.npoints[ray] = 1;
             A.stop_code[ray] = cs_flag;
             if (A.end_ray_vec)
@@ -158,6 +162,7 @@ rk4_trace_kernel(const DevParams P, const TraceArgs A) {
       }
       if (done) {
         if (stop >= 0) {  // ray_tracing.f90:252-260
+          const TraceArgs& A = cold_args(A_hot);
           A.npoints[ray] = nstep + 1;
           A.stop_code[ray] = stop;
           if (A.end_ray_vec)
@@ -173,14 +178,15 @@ rk4_trace_kernel(const DevParams P, const TraceArgs A) {
     if (done) {
       // a finished lane's points must leave LDS before the lane is re-used for another ray:
       // it drains its own column (once per ray; the coalesced path is the wave flush below)
-      stage.drain_own(A, nbuf, first_pt);
+      stage.drain_own(A_hot, nbuf, first_pt);
       nbuf = 0;
     }
     if (__any(nbuf == K)) {
-      stage.flush(A, nbuf, first_pt);
+      stage.flush(A_hot, nbuf, first_pt);
       nbuf = 0;
     }
     if (done) {
+      const TraceArgs& A = cold_args(A_hot);
       const unsigned nxt = atomicAdd(A.next_ray, 1u) + total_lanes;
       if (nxt < (unsigned)A.nray) {
         ray = (int)nxt;

@@ -59,7 +59,7 @@ __device__ static const double kGstr[14] = {
 
 template <int EQ, int NS, int DERIV, int NV, int K>
 __global__ void __launch_bounds__(256)
-sg_trace_kernel(const DevParams P, const TraceArgs A) {
+sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
@@ -75,7 +75,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A) {
 
   // ---- per-lane ray state -------------------------------------------------------------------
   int ray = blockIdx.x * blockDim.x + threadIdx.x;
-  bool alive = ray < A.nray;
+  bool alive = ray < A_hot.nray;
   bool need_init = alive;
   int pc = PC_CHECK;
   int nstep = 0;
@@ -102,6 +102,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A) {
 
   while (__any(alive)) {
     if (need_init) {  // ray_tracing.f90:77-93, SG_ode_m.f90:73-85
+      const TraceArgs& A = cold_args(A_hot);  // rays_trace.hpp
       initialize_ode_vector<EQ, NS, NV>(P, A.rvec0 + 3ll * ray, A.rindex_vec0 + 3ll * ray, vst);
 #pragma unroll
       for (int i = 0; i < NV; i++) win[i] = vst[i];
@@ -141,6 +142,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A) {
           nbuf++;
           fl &= ~FL_FIRST;
           if (cs_stop) {
+            const TraceArgs& A = cold_args(A_hot);
             A.npoints[ray] = 1;
             A.stop_code[ray] = cs_flag;
             if (A.end_ray_vec)
@@ -589,6 +591,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A) {
       }
 
       if (done && stop >= 0) {  // ray_tracing.f90:252-260
+        const TraceArgs& A = cold_args(A_hot);
         A.npoints[ray] = nstep + 1;
         A.stop_code[ray] = stop;
         if (A.end_ray_vec)
@@ -604,14 +607,15 @@ sg_trace_kernel(const DevParams P, const TraceArgs A) {
 
     // ---- wave-level: flush staged points, refill finished lanes --------------------------------
     if (done) {
-      stage.drain_own(A, nbuf, first_pt);
+      stage.drain_own(A_hot, nbuf, first_pt);
       nbuf = 0;
     }
     if (__any(nbuf == K)) {
-      stage.flush(A, nbuf, first_pt);
+      stage.flush(A_hot, nbuf, first_pt);
       nbuf = 0;
     }
     if (done) {
+      const TraceArgs& A = cold_args(A_hot);
       const unsigned nxt = atomicAdd(A.next_ray, 1u) + total_lanes;
       if (nxt < (unsigned)A.nray) {
         ray = (int)nxt;

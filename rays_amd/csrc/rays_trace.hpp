@@ -42,6 +42,25 @@ struct TraceArgs {
   unsigned int* __restrict__ next_ray;     // refill counter, zeroed before launch
 };
 
+// The trace kernels' signature is (DevParams, TraceArgs).  The eleven pointers of TraceArgs are
+// only needed where a ray starts or ends and where staged points are flushed; as plain kernel
+// arguments they are loaded once and then occupy 24 of the ~100 SGPRs across the whole wave loop,
+// which the hot RHS pays for with spill reloads (v_readlane_b32).  cold_args() re-reads the block
+// from the kernarg segment at the point of use instead (scalar loads behind an opaque zero offset,
+// so LLVM cannot hoist them back out of the loop).
+#ifdef RAYS_HOST_EMUL
+RAYS_DEV const TraceArgs& cold_args(const TraceArgs& A) { return A; }
+#else
+RAYS_DEV const TraceArgs& cold_args(const TraceArgs&) {
+  typedef const __attribute__((address_space(4))) char* kconst_ptr;
+  constexpr unsigned kOffset = (sizeof(DevParams) + alignof(TraceArgs) - 1) / alignof(TraceArgs) * alignof(TraceArgs);
+  unsigned z;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+  kconst_ptr kb = (kconst_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  return *reinterpret_cast<const TraceArgs*>((const char*)(kb + kOffset + z));
+}
+#endif
+
 // Per-wave LDS staging of recorded trajectory points.
 template <int NV, int K>
 struct PointStage {
@@ -58,7 +77,8 @@ struct PointStage {
   }
 
   // One lane writes out its own staged points (ray termination).
-  RAYS_DEV void drain_own(const TraceArgs& A, int nbuf, long long first_pt) {
+  RAYS_DEV void drain_own(const TraceArgs& A_, int nbuf, long long first_pt) {
+    const TraceArgs& A = cold_args(A_);
     for (int k = 0; k < nbuf; k++) {
       const double* p = base + (k * (NV + 1)) * kRowStride + lane;
 #pragma unroll
@@ -69,7 +89,8 @@ struct PointStage {
 
   // All 64 lanes call this together.  nbuf = points this lane has staged, first_pt = global point
   // index (ray*(nstep_max+1) + step) of its slot 0.
-  RAYS_DEV void flush(const TraceArgs& A, int nbuf, long long first_pt) {
+  RAYS_DEV void flush(const TraceArgs& A_, int nbuf, long long first_pt) {
+    const TraceArgs& A = cold_args(A_);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
