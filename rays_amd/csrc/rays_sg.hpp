@@ -44,10 +44,283 @@ enum : int {
   SEG_STOP         // ray finished with code `stop`
 };
 
+// One recorded trajectory point, written by its own lane: ray_vec(:, pt) and residual(pt).
 template <int NV>
-struct SgLane {
-  double phi[NV][17];
-  double psi[13], alpha[13], beta[13], sig[14], v[13], w[13], g[14];
+RAYS_DEV void record_point(const TraceArgs& A, long long pt, const double v[NV], double resid) {
+#pragma unroll
+  for (int c = 0; c < NV; c++) A.ray_vec[pt * NV + c] = v[c];
+  A.residual[pt] = resid;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-lane integrator storage.
+//
+// `step` keeps the coefficient vectors psi, alpha, beta, sig, g, v (<= 13 entries each) and the
+// divided differences phi(neqn,16) between calls, indexed by the lane's own order k.  As private
+// arrays they are scratch memory, and with one wave per SIMD every scratch access that is waited
+// for costs a full memory round trip (~1-2 us; 64k lanes x 2 KB of scratch live in L2/MALL):
+// the first version of this kernel spent ~100 us per trip there against ~3 us in the RHS.
+//
+// SG_ode restarts the integrator on every output interval (SG_ode_m.f90:118-122), so the order
+// stays low: k <= 4 in 99.5 % and k <= 6 in 99.97 % of the steps of the Solovev fans.  Storage is
+// therefore tiered by index, the fast tiers holding everything k <= 6 touches:
+//   coefficient entries 1..8        LDS, lane-interleaved (element e of lane L at col[e * 64])
+//   coefficient entries 9..13       private memory (scratch)
+//   phi rows 1..4                   registers: every loop over rows is unrolled over q = 1..4 with
+//                                   the lane's bounds as predicates and a wave-uniform skip
+//   phi rows 5..4+LR (LR = 30/nv)   LDS
+//   phi rows above                  private memory (scratch)
+// LDS per lane: 6 x 8 + LR x nv <= 78 doubles -> at most 156 KB per 4-wave workgroup, so the SG
+// kernel stages no trajectory points in LDS: it records one point per ~30 trips and the lane
+// writes it straight to HBM.
+// ---------------------------------------------------------------------------------------------
+// (the RAYS_SG_* overrides exist for tests/hip_emul, which shrinks the fast tiers so that ordinary
+// rays cross every tier boundary)
+#ifndef RAYS_SG_TIER
+#define RAYS_SG_TIER 8
+#endif
+#ifndef RAYS_SG_REG_ROWS
+#define RAYS_SG_REG_ROWS 2  // measured on the 256k-ray eqdsk fan: 2 | 4 | 6 | 8 register rows -> 119 | 125 | 168 | 320 ms
+#endif
+constexpr int kSgTier = RAYS_SG_TIER;  // coefficient entries held in LDS
+// LDS pointers carry their address space explicitly: the tiered accessors choose between an LDS
+// and a private location, and with generic pointers LLVM may merge the two loads into one load
+// through a selected flat pointer (slow, and hipcc 7.2 then fails in instruction selection).
+#ifdef RAYS_HOST_EMUL
+typedef double* sg_lds_ptr;
+#else
+typedef __attribute__((address_space(3))) double* sg_lds_ptr;
+#endif
+template <int NV>
+constexpr int sg_phi_lds_rows() {
+#ifdef RAYS_SG_LDS_ROWS
+  return RAYS_SG_LDS_ROWS;
+#else
+  return 30 / NV < 1 ? 1 : 30 / NV;
+#endif
+}
+constexpr int kSgPhiRegRows = RAYS_SG_REG_ROWS;
+
+struct SgCoef {
+  enum { PSI = 0, ALPHA, BETA, SIG, G, V, kArrays };
+  sg_lds_ptr col;               // this lane's LDS column
+  double (*far)[14 - kSgTier];  // entries above the LDS tier (.. 14), private memory of the kernel
+
+  struct Ref {  // reads / writes one entry through the tier it lives in
+    const SgCoef* s;
+    int arr, i;
+    RAYS_DEV operator double() const {
+      return i <= kSgTier ? s->col[(arr * kSgTier + i - 1) * kWave] : s->far[arr][i - kSgTier - 1];
+    }
+    RAYS_DEV const Ref& operator=(double x) const {
+      if (i <= kSgTier)
+        s->col[(arr * kSgTier + i - 1) * kWave] = x;
+      else
+        s->far[arr][i - kSgTier - 1] = x;
+      return *this;
+    }
+    RAYS_DEV const Ref& operator=(const Ref& o) const { return *this = (double)o; }  // copies the VALUE
+  };
+  RAYS_DEV Ref psi(int i) const { return Ref{this, PSI, i}; }      // i = 1..12
+  RAYS_DEV Ref alpha(int i) const { return Ref{this, ALPHA, i}; }  // i = 1..12
+  RAYS_DEV Ref beta(int i) const { return Ref{this, BETA, i}; }    // i = 1..12
+  RAYS_DEV Ref sig(int i) const { return Ref{this, SIG, i}; }      // i = 1..13
+  RAYS_DEV Ref g(int i) const { return Ref{this, G, i}; }          // i = 1..13
+  RAYS_DEV Ref v(int i) const { return Ref{this, V, i}; }          // i = 1..12
+  // intrp runs when the interval is complete and the integrator is about to be restarted, so its
+  // work vectors w(1:14), g(1:13) (ode_RAYS.f90:1300-1301) reuse the alpha and sig storage.
+  RAYS_DEV Ref wi(int i) const { return Ref{this, ALPHA, i}; }  // i = 1..14
+  RAYS_DEV Ref gi(int i) const { return Ref{this, SIG, i}; }    // i = 1..13
+};
+
+template <int NV>
+struct SgLds {  // LDS doubles per lane / per wave
+  static constexpr int kPhiBase = SgCoef::kArrays * kSgTier;
+  static constexpr int kPerLane = kPhiBase + sg_phi_lds_rows<NV>() * NV;
+  static constexpr int kDoublesPerWave = kPerLane * kWave;
+};
+
+// Divided differences phi(neqn,16) (ode_RAYS.f90:668), tiered as described above.
+template <int NV, int R, int LR>
+struct SgPhi {
+  static_assert(R >= 2 && LR >= 1, "rows 1 and 2 are addressed directly (start of an interval)");
+  double lo[R][NV];  // rows 1..R: registers (static indices only)
+  sg_lds_ptr mid;    // rows R+1..R+LR: LDS, element (row, l) of this lane at mid[((row-R-1)*NV + l) * 64]
+  double (*hi)[NV];  // rows R+LR+1..16 -> hi[row - R - LR - 1]: a SEPARATE private array of the kernel,
+                     // so that its dynamic indexing does not drag lo[] into scratch memory with it
+
+  RAYS_DEV void load_far(int i, double out[NV]) const {  // i > R
+    const int r = i - R - 1;
+    if (r < LR) {
+#pragma unroll
+      for (int l = 0; l < NV; l++) out[l] = mid[(r * NV + l) * kWave];
+    } else {
+#pragma unroll
+      for (int l = 0; l < NV; l++) out[l] = hi[r - LR][l];
+    }
+  }
+  RAYS_DEV void store_far(int i, const double in[NV]) {  // i > R
+    const int r = i - R - 1;
+    if (r < LR) {
+#pragma unroll
+      for (int l = 0; l < NV; l++) mid[(r * NV + l) * kWave] = in[l];
+    } else {
+#pragma unroll
+      for (int l = 0; l < NV; l++) hi[r - LR][l] = in[l];
+    }
+  }
+  RAYS_DEV void get(int i, double out[NV]) const {  // out = phi(:, i), i dynamic
+#pragma unroll
+    for (int l = 0; l < NV; l++) out[l] = 0.;
+#pragma unroll
+    for (int q = 1; q <= R; q++) {
+      if (!__any(i == q)) continue;
+      if (i == q) {
+#pragma unroll
+        for (int l = 0; l < NV; l++) out[l] = lo[q - 1][l];
+      }
+    }
+    if (i > R) load_far(i, out);
+  }
+  RAYS_DEV void set(int i, const double in[NV]) {  // phi(:, i) = in, i dynamic
+#pragma unroll
+    for (int q = 1; q <= R; q++) {
+      if (!__any(i == q)) continue;
+      if (i == q) {
+#pragma unroll
+        for (int l = 0; l < NV; l++) lo[q - 1][l] = in[l];
+      }
+    }
+    if (i > R) store_far(i, in);
+  }
+  // phi(:, i) = beta(i) * phi(:, i), i = a..b                       (ode_RAYS.f90:992-996)
+  template <class Beta>
+  RAYS_DEV void scale(int a, int b, Beta beta) {
+#pragma unroll
+    for (int q = 1; q <= R; q++) {
+      const bool on = q >= a && q <= b;
+      if (!__any(on)) continue;
+      if (on) {
+        const double bq = beta(q);
+#pragma unroll
+        for (int l = 0; l < NV; l++) lo[q - 1][l] = bq * lo[q - 1][l];
+      }
+    }
+    for (int i = (a > R + 1 ? a : R + 1); i <= b; i++) {
+      const double bq = beta(i);
+      double row[NV];
+      load_far(i, row);
+#pragma unroll
+      for (int l = 0; l < NV; l++) row[l] = bq * row[l];
+      store_far(i, row);
+    }
+  }
+  // predictor (:1003-1011), i = k..1:  p += phi(:,i)*g(i); phi(:,i) += phi(:,i+1).
+  // phi(:,k+1) has just been zeroed; `up` carries the updated row above.
+  template <class G>
+  RAYS_DEV void predict(int k, G g, double pp[NV]) {
+    double up[NV];
+#pragma unroll
+    for (int l = 0; l < NV; l++) up[l] = 0.;
+    for (int i = k; i > R; i--) {
+      const double gg = g(i);
+      double row[NV];
+      load_far(i, row);
+#pragma unroll
+      for (int l = 0; l < NV; l++) {
+        pp[l] = pp[l] + row[l] * gg;
+        row[l] = row[l] + up[l];
+        up[l] = row[l];
+      }
+      store_far(i, row);
+    }
+#pragma unroll
+    for (int q = R; q >= 1; q--) {
+      const bool on = q <= k;
+      if (!__any(on)) continue;
+      if (on) {
+        const double gg = g(q);
+#pragma unroll
+        for (int l = 0; l < NV; l++) {
+          double r = lo[q - 1][l];
+          pp[l] = pp[l] + r * gg;
+          r = r + up[l];
+          lo[q - 1][l] = r;
+          up[l] = r;
+        }
+      }
+    }
+  }
+  // failed step (:1090-1094), i = 1..k ascending:  phi(:,i) = (phi(:,i) - phi(:,i+1)) / beta(i)
+  template <class Beta>
+  RAYS_DEV void restore(int k, Beta beta) {
+    double nxt[NV];  // phi(:, R+1), not yet modified when row R is restored
+#pragma unroll
+    for (int l = 0; l < NV; l++) nxt[l] = 0.;
+    if (k >= R) load_far(R + 1, nxt);
+#pragma unroll
+    for (int q = 1; q <= R; q++) {
+      const bool on = q <= k;
+      if (!__any(on)) continue;
+      if (on) {
+        const Recip b = make_recip(beta(q));
+#pragma unroll
+        for (int l = 0; l < NV; l++) {
+          const double above = q < R ? lo[q < R ? q : 0][l] : nxt[l];  // phi(:, q+1), old value
+          lo[q - 1][l] = div(lo[q - 1][l] - above, b);
+        }
+      }
+    }
+    for (int i = R + 1; i <= k; i++) {
+      const Recip b = make_recip(beta(i));
+      double row[NV], abv[NV];
+      load_far(i, row);
+      load_far(i + 1, abv);
+#pragma unroll
+      for (int l = 0; l < NV; l++) row[l] = div(row[l] - abv[l], b);
+      store_far(i, row);
+    }
+  }
+  // phi(:, i) += d, i = 1..k                                         (:1160-1164)
+  RAYS_DEV void add(int k, const double d[NV]) {
+#pragma unroll
+    for (int q = 1; q <= R; q++) {
+      const bool on = q <= k;
+      if (!__any(on)) continue;
+      if (on) {
+#pragma unroll
+        for (int l = 0; l < NV; l++) lo[q - 1][l] = lo[q - 1][l] + d[l];
+      }
+    }
+    for (int i = R + 1; i <= k; i++) {
+      double row[NV];
+      load_far(i, row);
+#pragma unroll
+      for (int l = 0; l < NV; l++) row[l] = row[l] + d[l];
+      store_far(i, row);
+    }
+  }
+  // intrp (:1343-1349), i = ki..1:  yout += g(i) * phi(:, i)
+  template <class G>
+  RAYS_DEV void interp(int ki, G g, double yout[NV]) const {
+    for (int i = ki; i > R; i--) {
+      const double gg = g(i);
+      double row[NV];
+      load_far(i, row);
+#pragma unroll
+      for (int l = 0; l < NV; l++) yout[l] = yout[l] + gg * row[l];
+    }
+#pragma unroll
+    for (int q = R; q >= 1; q--) {
+      const bool on = q <= ki;
+      if (!__any(on)) continue;
+      if (on) {
+        const double gg = g(q);
+#pragma unroll
+        for (int l = 0; l < NV; l++) yout[l] = yout[l] + gg * lo[q - 1][l];
+      }
+    }
+  }
 };
 
 // gstr(1:13) -- single-precision literals widened to double (ode_RAYS.f90:776-779)
@@ -57,15 +330,22 @@ __device__ static const double kGstr[14] = {
     (double)0.00789e+00f, (double)0.00679e+00f, (double)0.00592e+00f, (double)0.00524e+00f,
     (double)0.00468e+00f};
 
-template <int EQ, int NS, int DERIV, int NV, int K>
+template <int EQ, int NS, int DERIV, int NV>
 __global__ void __launch_bounds__(256)
 sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
-  PointStage<NV, K> stage;
-  stage.base = lds + wave * PointStage<NV, K>::kDoublesPerWave;
-  stage.lane = lane;
+  constexpr int RR = kSgPhiRegRows, LR = sg_phi_lds_rows<NV>();
+  const sg_lds_ptr lane_lds = (sg_lds_ptr)(lds + wave * SgLds<NV>::kDoublesPerWave + lane);
+  double coef_far[SgCoef::kArrays][14 - kSgTier];
+  SgCoef S;
+  S.col = lane_lds;
+  S.far = coef_far;
+  double phi_far[17 - RR - LR][NV];
+  SgPhi<NV, RR, LR> F;  // divided differences phi(neqn,16)
+  F.mid = lane_lds + SgLds<NV>::kPhiBase * kWave;
+  F.hi = phi_far;
 
   const unsigned total_lanes = gridDim.x * blockDim.x;
   const long long npt = (long long)P.nstep_max + 1;
@@ -81,14 +361,12 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
   int nstep = 0;
   double sout = 0.;
   double vst[NV];   // v: the ray state at the last completed output point (y of SG_ode)
-  double win[NV];   // RHS input of the current trip
   double last_resid = 0., prev_resid = 0., maxr = -1.7976931348623157e308;
-  int nbuf = 0;
-  long long first_pt = 0;
 
   // ---- per-lane integrator state (de / step locals that live across RHS evaluations) ----------
-  SgLane<NV> S;
-  double yy[NV], wt[NV], pp[NV], yp[NV];
+  double yy[NV], pp[NV];  // (yp of `step` is always the f of the current trip: not kept)
+  // wt(l) with its reciprocal: ~6 nv quotients x/wt(l) per step share it (rays_device.hpp: Recip)
+  Recip wt[NV];
   double t = 0., tout = 0., x = 0., h = 0., hold = 0., eps = 0.;
   double rel_err = 0., abs_err = 0., releps = 0., abseps = 0., absdel = 0., tend = 0.;
   double p5eps = 0., round_ = 0., xold = 0., absh = 0., erk = 0., erkm1 = 0.;
@@ -98,14 +376,12 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
   // them the register allocator spills lane masks inside divergent control flow.
   unsigned fl = FL_START | FL_PHASE1 | FL_NORND | FL_FIRST;
 #pragma unroll
-  for (int i = 0; i < NV; i++) vst[i] = win[i] = yy[i] = wt[i] = pp[i] = yp[i] = 0.;
+  for (int i = 0; i < NV; i++) vst[i] = yy[i] = pp[i] = wt[i].d = wt[i].rc = 0.;
 
   while (__any(alive)) {
     if (need_init) {  // ray_tracing.f90:77-93, SG_ode_m.f90:73-85
       const TraceArgs& A = cold_args(A_hot);  // rays_trace.hpp
       initialize_ode_vector<EQ, NS, NV>(P, A.rvec0 + 3ll * ray, A.rindex_vec0 + 3ll * ray, vst);
-#pragma unroll
-      for (int i = 0; i < NV; i++) win[i] = vst[i];
       pc = PC_CHECK;
       fl |= FL_FIRST;
       nstep = 0;
@@ -123,7 +399,22 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
     double f[NV], resid = 0.;
     int code = 0, cs_flag = 0;
     bool cs_stop = false;
-    if (alive) rhs_eval<EQ, NS, DERIV, NV>(P, win, pc == PC_CHECK, resid, cs_flag, cs_stop, code, f);
+    // Phase alignment.  A lane alternates between the predictor evaluation (PC_F2, continued by
+    // the short AFTER_F2 segment) and the corrector / start evaluations (continued by AFTER_F3 ->
+    // DE_TOP -> COEF, the long part).  With lanes in both phases the wave would run ALL the
+    // continuation code on every trip.  Each trip therefore serves only the phase most lanes are
+    // in; the others sit the trip out (their RHS input is unchanged, so nothing is lost but the
+    // slot).  Served lanes move to the other phase, so the wave falls into step after one trip and
+    // a lane idles about once per output interval (an interval has an odd number of evaluations).
+    const bool in_f2 = pc == PC_F2;
+    const int n_f2 = __popcll(__ballot(alive && in_f2)), n_other = __popcll(__ballot(alive && !in_f2));
+    const bool serve_f2 = n_f2 > n_other;
+    const bool act = alive && (in_f2 == serve_f2);
+    // RHS input: the recorded state (PC_CHECK), the predicted p (PC_F2), else the current yy
+    double win[NV];
+#pragma unroll
+    for (int l = 0; l < NV; l++) win[l] = pc == PC_F2 ? pp[l] : (pc == PC_CHECK ? vst[l] : yy[l]);
+    if (act) rhs_eval<EQ, NS, DERIV, NV>(P, win, pc == PC_CHECK, resid, cs_flag, cs_stop, code, f);
 
     // ---- per-lane continuation -------------------------------------------------------------------
     int stop = 0;
@@ -131,15 +422,13 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
 #ifdef RAYS_SG_DEBUG
     double dbg[7] = {-1, -1, -1, -1, -1, -1, -1};
 #endif
-    if (alive) {
+    if (act) {
       int seg;
       int have_f = 0;  // f(x, yy) for start = true is already in f[]
       if (pc == PC_CHECK) {
         seg = SEG_DE_BEGIN;
         if (fl & FL_FIRST) {  // ray_tracing.f90:92-112
-          if (nbuf == 0) first_pt = (long long)ray * npt;
-          stage.put(nbuf, vst, 0.);
-          nbuf++;
+          record_point<NV>(cold_args(A_hot), (long long)ray * npt, vst, 0.);
           fl &= ~FL_FIRST;
           if (cs_stop) {
             const TraceArgs& A = cold_args(A_hot);
@@ -155,17 +444,13 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
             seg = SEG_WAIT;
           }
         } else {
-          // the interval completed: win is y(tout)  (ray_tracing.f90:212-243)
-#pragma unroll
-          for (int i = 0; i < NV; i++) vst[i] = win[i];
+          // the interval completed: vst is y(tout)  (ray_tracing.f90:212-243)
           if (cs_stop) {
             stop = cs_flag;
             seg = SEG_STOP;
           } else {
             nstep = nstep + 1;
-            if (nbuf == 0) first_pt = (long long)ray * npt + nstep;
-            stage.put(nbuf, vst, resid);
-            nbuf++;
+            record_point<NV>(cold_args(A_hot), (long long)ray * npt + nstep, vst, resid);
             if (fabs(last_resid) > maxr) maxr = fabs(last_resid);
             prev_resid = last_resid;
             last_resid = resid;
@@ -193,239 +478,11 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
         seg = SEG_AFTER_F3;
       }
 
+      // Continuation segments in pipeline order: a lane falls through AFTER_F3 -> DE_TOP -> COEF (or
+      // CHECK -> DE_BEGIN -> DE_TOP -> START_DONE -> COEF) in ONE pass, so each segment's code runs
+      // at most once per trip for the whole wave; only the rare DE_TOP -> CRASH edge goes round again.
       while (seg != SEG_WAIT) {
-        if (seg == SEG_STOP) {
-          done = 1;
-#ifdef RAYS_SG_DEBUG
-          dbg[0] = (double)stop; dbg[1] = (double)pc; dbg[2] = (double)nostep; dbg[3] = (double)k;
-          dbg[4] = (double)code; dbg[5] = t; dbg[6] = tout;
-#endif
-          seg = SEG_WAIT;
-        } else if (seg == SEG_DE_BEGIN) {
-          // ---- de parameter tests + restart (ode_RAYS.f90:423-505); y == vst, t, tout set ----
-          if (t == tout) {
-            stop = RAYS_STOP_SG_T_EQ_TOUT;
-            seg = SEG_STOP;
-          } else if (rel_err < 0.0 || abs_err < 0.0) {
-            stop = RAYS_STOP_SG_NEG_ERR;
-            seg = SEG_STOP;
-          } else {
-            eps = fmax(rel_err, abs_err);
-            if (eps <= 0.0) {
-              stop = RAYS_STOP_SG_EPS_LE_0;
-              seg = SEG_STOP;
-            } else {
-              const double del = tout - t;
-              absdel = fabs(del);
-              tend = t + 10.0 * del;  // :485
-              nostep = 0;
-              kle4 = 0;
-              fl &= ~FL_STIFF;
-              releps = rel_err / eps;
-              abseps = abs_err / eps;
-              fl |= FL_START;  // :497-505
-              x = t;
-#pragma unroll
-              for (int i = 0; i < NV; i++) yy[i] = vst[i];
-              h = copysign(fmax(fabs(tout - x), fouru * fabs(x)), tout - x);
-              seg = SEG_DE_TOP;
-            }
-          }
-        } else if (seg == SEG_DE_TOP) {
-          if (absdel <= fabs(x - t)) {
-            // ---- intrp (ode_RAYS.f90:1235-1362) -> y(tout); interval done (:511-518) ----
-            double gi[14], rho[14], wi[15];
-            const double hi = tout - x;
-            const int ki = kold + 1;
-            for (int i = 1; i <= ki; i++) wi[i] = 1.0 / (double)i;
-            gi[1] = 1.0;
-            rho[1] = 1.0;
-            double term = 0.0;
-            for (int j = 2; j <= ki; j++) {
-              const double psijm1 = S.psi[j - 1];
-              const double gamma = (hi + term) / psijm1;
-              const double eta = hi / psijm1;
-              for (int i = 1; i <= ki + 1 - j; i++) wi[i] = gamma * wi[i] - eta * wi[i + 1];
-              gi[j] = wi[1];
-              rho[j] = gamma * rho[j - 1];
-              term = psijm1;
-            }
-            double yout[NV];
-#pragma unroll
-            for (int l = 0; l < NV; l++) yout[l] = 0.0;
-            for (int j = 1; j <= ki; j++) {
-              const int i = ki + 1 - j;
-              const double gg = gi[i];
-#pragma unroll
-              for (int l = 0; l < NV; l++) yout[l] = yout[l] + gg * S.phi[l][i];
-            }
-#pragma unroll
-            for (int l = 0; l < NV; l++) win[l] = yy[l] + hi * yout[l];
-            t = tout;
-            pc = PC_CHECK;
-            seg = SEG_WAIT;
-          } else if (maxnum <= nostep) {  // :536-548
-            stop = (fl & FL_STIFF) ? RAYS_STOP_SG_STIFF : RAYS_STOP_SG_MAXNUM;
-#pragma unroll
-            for (int i = 0; i < NV; i++) vst[i] = yy[i];  // y = yy; t = x
-            t = x;
-            seg = SEG_STOP;
-          } else {
-            h = copysign(fmin(fabs(h), fabs(tend - x)), h);  // :552-553
-#pragma unroll
-            for (int l = 0; l < NV; l++) wt[l] = releps * fabs(yy[l]) + abseps;
-            // ---- step entry (ode_RAYS.f90:833-885) ----
-            if (fabs(h) < fouru * fabs(x)) {
-              h = copysign(fouru * fabs(x), h);
-              seg = SEG_CRASH;
-            } else {
-              p5eps = 0.5 * eps;
-              double sm = 0.;
-#pragma unroll
-              for (int l = 0; l < NV; l++) {
-                const double q = yy[l] / wt[l];
-                sm += q * q;
-              }
-              round_ = twou * sqrt(sm);  // :844
-              if (p5eps < round_) {
-                eps = 2.0 * round_ * (1.0 + fouru);
-                seg = SEG_CRASH;
-              } else {
-                S.g[1] = 1.0;
-                S.g[2] = 0.5;
-                S.sig[1] = 1.0;
-                if (fl & FL_START) {
-                  if (have_f) {
-                    seg = SEG_START_DONE;
-                  } else {  // f(x, yy) needed (:860)
-#pragma unroll
-                    for (int l = 0; l < NV; l++) win[l] = yy[l];
-                    pc = PC_F1;
-                    seg = SEG_WAIT;
-                  }
-                } else {
-                  ifail = 0;
-                  seg = SEG_COEF;
-                }
-              }
-            }
-          }
-        } else if (seg == SEG_START_DONE) {
-          have_f = 0;
-          if (code) {  // :863 stop inside f: y, t untouched
-            stop = code;
-            seg = SEG_STOP;
-          } else {  // :865-885
-            double sm = 0.;
-#pragma unroll
-            for (int l = 0; l < NV; l++) {
-              yp[l] = f[l];
-              S.phi[l][1] = f[l];
-              S.phi[l][2] = 0.0;
-              const double q = f[l] / wt[l];
-              sm += q * q;
-            }
-            const double total = sqrt(sm);
-            absh = fabs(h);
-            if (eps < 16.0 * total * h * h) absh = 0.25 * sqrt(eps / total);
-            h = copysign(fmax(absh, fouru * fabs(x)), h);
-            hold = 0.0;
-            k = 1;
-            kold = 0;
-            fl &= ~FL_START;
-            fl |= FL_PHASE1;
-            fl |= FL_NORND;
-            if (p5eps <= 100.0 * round_) {
-              fl &= ~FL_NORND;
-#pragma unroll
-              for (int l = 0; l < NV; l++) S.phi[l][15] = 0.0;
-            }
-            ifail = 0;
-            seg = SEG_COEF;
-          }
-        } else if (seg == SEG_COEF) {
-          // ---- coefficients + predictor (ode_RAYS.f90:892-1015) ----
-          const int kp1 = k + 1, kp2 = k + 2;
-          if (h != hold) ns = 0;
-          if (ns <= kold) ns = ns + 1;
-          const int nsp1 = ns + 1;
-          if (ns <= k) {
-            S.beta[ns] = 1.0;
-            S.alpha[ns] = 1.0 / (double)ns;
-            double temp1 = h * (double)ns;
-            S.sig[nsp1] = 1.0;
-            for (int i = nsp1; i <= k; i++) {
-              const double temp2 = S.psi[i - 1];
-              S.psi[i - 1] = temp1;
-              S.beta[i] = S.beta[i - 1] * S.psi[i - 1] / temp2;
-              temp1 = temp2 + h;
-              S.alpha[i] = h / temp1;
-              S.sig[i + 1] = (double)i * S.alpha[i] * S.sig[i];
-            }
-            S.psi[k] = temp1;
-            if (ns <= 1) {
-              for (int iq = 1; iq <= k; iq++) {
-                S.v[iq] = 1.0 / (double)(iq * (iq + 1));
-                S.w[iq] = S.v[iq];
-              }
-            } else {
-              if (kold < k) {
-                S.v[k] = 1.0 / (double)(k * kp1);
-                for (int j = 1; j <= ns - 2; j++) {
-                  const int i = k - j;
-                  S.v[i] = S.v[i] - S.alpha[j + 1] * S.v[i + 1];
-                }
-              }
-              for (int iq = 1; iq <= kp1 - ns; iq++) {
-                S.v[iq] = S.v[iq] - S.alpha[ns] * S.v[iq + 1];
-                S.w[iq] = S.v[iq];
-              }
-              S.g[nsp1] = S.w[1];
-            }
-            for (int i = ns + 2; i <= kp1; i++) {
-              for (int iq = 1; iq <= kp2 - i; iq++) S.w[iq] = S.w[iq] - S.alpha[i - 1] * S.w[iq + 1];
-              S.g[i] = S.w[1];
-            }
-          }
-          for (int i = nsp1; i <= k; i++) {
-            const double b = S.beta[i];
-#pragma unroll
-            for (int l = 0; l < NV; l++) S.phi[l][i] = b * S.phi[l][i];
-          }
-#pragma unroll
-          for (int l = 0; l < NV; l++) {
-            S.phi[l][kp2] = S.phi[l][kp1];
-            S.phi[l][kp1] = 0.0;
-            pp[l] = 0.0;
-          }
-          for (int j = 1; j <= k; j++) {
-            const int i = kp1 - j;
-            const double gg = S.g[i];
-#pragma unroll
-            for (int l = 0; l < NV; l++) {
-              pp[l] = pp[l] + S.phi[l][i] * gg;
-              S.phi[l][i] = S.phi[l][i] + S.phi[l][i + 1];
-            }
-          }
-          if (!(fl & FL_NORND)) {
-#pragma unroll
-            for (int l = 0; l < NV; l++) {
-              const double tau = h * pp[l] - S.phi[l][15];
-              pp[l] = yy[l] + tau;
-              S.phi[l][16] = (pp[l] - yy[l]) - tau;
-            }
-          } else {
-#pragma unroll
-            for (int l = 0; l < NV; l++) pp[l] = yy[l] + h * pp[l];
-          }
-          xold = x;
-          x = x + h;
-          absh = fabs(h);
-#pragma unroll
-          for (int l = 0; l < NV; l++) win[l] = pp[l];
-          pc = PC_F2;
-          seg = SEG_WAIT;
-        } else if (seg == SEG_AFTER_F2) {
+        if (seg == SEG_AFTER_F2) {
           if (code) {  // :1020
             stop = code;
             seg = SEG_STOP;
@@ -435,25 +492,27 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
             double erkm2 = 0.0;
             erkm1 = 0.0;
             erk = 0.0;
+            double rk[NV], rkm1[NV];  // phi(:,k), phi(:,k-1)
+            F.get(k, rk);
+            F.get(km1, rkm1);
 #pragma unroll
             for (int l = 0; l < NV; l++) {
-              yp[l] = f[l];
-              const double ph1 = S.phi[l][1];
+              const double ph1 = F.lo[0][l];
               if (0 < km2) {
-                const double q = (S.phi[l][km1] + yp[l] - ph1) / wt[l];
+                const double q = div(rkm1[l] + f[l] - ph1, wt[l]);
                 erkm2 = erkm2 + q * q;
               }
               if (0 <= km2) {
-                const double q = (S.phi[l][k] + yp[l] - ph1) / wt[l];
+                const double q = div(rk[l] + f[l] - ph1, wt[l]);
                 erkm1 = erkm1 + q * q;
               }
-              const double q = (yp[l] - ph1) / wt[l];
+              const double q = div(f[l] - ph1, wt[l]);
               erk = erk + q * q;
             }
-            if (0 < km2) erkm2 = absh * S.sig[km1] * kGstr[km2] * sqrt(erkm2);
-            if (0 <= km2) erkm1 = absh * S.sig[k] * kGstr[km1] * sqrt(erkm1);
-            const double err = absh * sqrt(erk) * (S.g[k] - S.g[kp1]);
-            erk = absh * sqrt(erk) * S.sig[kp1] * kGstr[k];
+            if (0 < km2) erkm2 = absh * S.sig(km1) * kGstr[km2] * sqrt(erkm2);
+            if (0 <= km2) erkm1 = absh * S.sig(k) * kGstr[km1] * sqrt(erkm1);
+            const double err = absh * sqrt(erk) * (S.g(k) - S.g(kp1));
+            erk = absh * sqrt(erk) * S.sig(kp1) * kGstr[k];
             knew = k;
             if (0 < km2) {
               if (fmax(erkm1, erkm2) <= erk) knew = km1;
@@ -464,32 +523,26 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
               // ---- successful: correct (ode_RAYS.f90:1128-1142) ----
               kold = k;
               hold = h;
-              const double hg = h * S.g[kp1];
+              const double hg = h * S.g(kp1);
               if (!(fl & FL_NORND)) {
 #pragma unroll
                 for (int l = 0; l < NV; l++) {
-                  const double rho = hg * (yp[l] - S.phi[l][1]) - S.phi[l][16];
+                  const double rho = hg * (f[l] - F.lo[0][l]) - F.hi[16 - RR - LR - 1][l];
                   yy[l] = pp[l] + rho;
-                  S.phi[l][15] = (yy[l] - pp[l]) - rho;
+                  F.hi[15 - RR - LR - 1][l] = (yy[l] - pp[l]) - rho;
                 }
               } else {
 #pragma unroll
-                for (int l = 0; l < NV; l++) yy[l] = pp[l] + hg * (yp[l] - S.phi[l][1]);
+                for (int l = 0; l < NV; l++) yy[l] = pp[l] + hg * (f[l] - F.lo[0][l]);
               }
-#pragma unroll
-              for (int l = 0; l < NV; l++) win[l] = yy[l];
               pc = PC_F3;
               seg = SEG_WAIT;
             } else {
               // ---- failed step: restore, shrink (ode_RAYS.f90:1086-1120) ----
               fl &= ~FL_PHASE1;
               x = xold;
-              for (int i = 1; i <= k; i++) {
-                const double b = S.beta[i];
-#pragma unroll
-                for (int l = 0; l < NV; l++) S.phi[l][i] = (S.phi[l][i] - S.phi[l][i + 1]) / b;
-              }
-              for (int i = 2; i <= k; i++) S.psi[i - 1] = S.psi[i] - h;
+              F.restore(k, [&](int i) { return S.beta(i); });
+              for (int i = 2; i <= k; i++) S.psi(i - 1) = S.psi(i) - h;
               ifail = ifail + 1;
               double temp2 = 0.5;
               if (3 < ifail) {
@@ -507,23 +560,24 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
               }
             }
           }
-        } else if (seg == SEG_AFTER_F3) {
+        }
+        if (seg == SEG_AFTER_F3) {
           if (code) {  // :1145
             stop = code;
             seg = SEG_STOP;
           } else {
             // ---- update differences, choose order and step (ode_RAYS.f90:1151-1231) ----
             const int kp1 = k + 1, kp2 = k + 2, km1 = k - 1;
+            double d1[NV], d2[NV];  // new phi(:,kp1), phi(:,kp2)
+            F.get(kp2, d2);
 #pragma unroll
             for (int l = 0; l < NV; l++) {
-              yp[l] = f[l];
-              S.phi[l][kp1] = yp[l] - S.phi[l][1];
-              S.phi[l][kp2] = S.phi[l][kp1] - S.phi[l][kp2];
+              d1[l] = f[l] - F.lo[0][l];
+              d2[l] = d1[l] - d2[l];
             }
-            for (int i = 1; i <= k; i++) {
-#pragma unroll
-              for (int l = 0; l < NV; l++) S.phi[l][i] = S.phi[l][i] + S.phi[l][kp1];
-            }
+            F.set(kp1, d1);
+            F.set(kp2, d2);
+            F.add(k, d1);
             double erkp1 = 0.0;
             if (knew == km1 || k == 12) fl &= ~FL_PHASE1;
             if (fl & FL_PHASE1) {
@@ -535,7 +589,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
             } else if (kp1 <= ns) {
 #pragma unroll
               for (int l = 0; l < NV; l++) {
-                const double q = S.phi[l][kp2] / wt[l];
+                const double q = div(d2[l], wt[l]);
                 erkp1 = erkp1 + q * q;
               }
               erkp1 = absh * kGstr[kp1] * sqrt(erkp1);
@@ -573,7 +627,8 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
             if (50 <= kle4) fl |= FL_STIFF;
             seg = SEG_DE_TOP;
           }
-        } else {  // SEG_CRASH: de returns iflag = 3 (ode_RAYS.f90:566-575), SG_ode_m.f90:139-149
+        }
+        if (seg == SEG_CRASH) {  // de returns iflag = 3 (ode_RAYS.f90:566-575), SG_ode_m.f90:139-149
           rel_err = eps * releps;
           abs_err = eps * abseps;
 #pragma unroll
@@ -587,6 +642,248 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
             have_f = 0;
             seg = SEG_DE_BEGIN;
           }
+        }
+        if (seg == SEG_DE_BEGIN) {
+          // ---- de parameter tests + restart (ode_RAYS.f90:423-505); y == vst, t, tout set ----
+          if (t == tout) {
+            stop = RAYS_STOP_SG_T_EQ_TOUT;
+            seg = SEG_STOP;
+          } else if (rel_err < 0.0 || abs_err < 0.0) {
+            stop = RAYS_STOP_SG_NEG_ERR;
+            seg = SEG_STOP;
+          } else {
+            eps = fmax(rel_err, abs_err);
+            if (eps <= 0.0) {
+              stop = RAYS_STOP_SG_EPS_LE_0;
+              seg = SEG_STOP;
+            } else {
+              const double del = tout - t;
+              absdel = fabs(del);
+              tend = t + 10.0 * del;  // :485
+              nostep = 0;
+              kle4 = 0;
+              fl &= ~FL_STIFF;
+              releps = rel_err / eps;
+              abseps = abs_err / eps;
+              fl |= FL_START;  // :497-505
+              x = t;
+#pragma unroll
+              for (int i = 0; i < NV; i++) yy[i] = vst[i];
+              h = copysign(fmax(fabs(tout - x), fouru * fabs(x)), tout - x);
+              seg = SEG_DE_TOP;
+            }
+          }
+        }
+        if (seg == SEG_DE_TOP) {
+          if (absdel <= fabs(x - t)) {
+            // ---- intrp (ode_RAYS.f90:1235-1362) -> y(tout); interval done (:511-518) ----
+            // (the rho recurrence :1331 only feeds ypout, which SG_ode discards)
+            const double hi = tout - x;
+            const int ki = kold + 1;
+            for (int i = 1; i <= ki; i++) S.wi(i) = 1.0 / (double)i;
+            S.gi(1) = 1.0;
+            double term = 0.0;
+            for (int j = 2; j <= ki; j++) {
+              const double psijm1 = S.psi(j - 1);
+              const Recip rpsi = make_recip(psijm1);
+              const double gamma = div(hi + term, rpsi);
+              const double eta = div(hi, rpsi);
+              for (int i = 1; i <= ki + 1 - j; i++) S.wi(i) = gamma * S.wi(i) - eta * S.wi(i + 1);
+              S.gi(j) = S.wi(1);
+              term = psijm1;
+            }
+            double yout[NV];
+#pragma unroll
+            for (int l = 0; l < NV; l++) yout[l] = 0.0;
+            F.interp(ki, [&](int i) { return S.gi(i); }, yout);
+#pragma unroll
+            for (int l = 0; l < NV; l++) vst[l] = yy[l] + hi * yout[l];  // y = yout
+            t = tout;
+            pc = PC_CHECK;
+            seg = SEG_WAIT;
+          } else if (maxnum <= nostep) {  // :536-548
+            stop = (fl & FL_STIFF) ? RAYS_STOP_SG_STIFF : RAYS_STOP_SG_MAXNUM;
+#pragma unroll
+            for (int i = 0; i < NV; i++) vst[i] = yy[i];  // y = yy; t = x
+            t = x;
+            seg = SEG_STOP;
+          } else {
+            h = copysign(fmin(fabs(h), fabs(tend - x)), h);  // :552-553
+#pragma unroll
+            for (int l = 0; l < NV; l++) wt[l] = make_recip(releps * fabs(yy[l]) + abseps);
+            // ---- step entry (ode_RAYS.f90:833-885) ----
+            if (fabs(h) < fouru * fabs(x)) {
+              h = copysign(fouru * fabs(x), h);
+              seg = SEG_CRASH;
+            } else {
+              p5eps = 0.5 * eps;
+              double sm = 0.;
+#pragma unroll
+              for (int l = 0; l < NV; l++) {
+                const double q = div(yy[l], wt[l]);
+                sm += q * q;
+              }
+              round_ = twou * sqrt(sm);  // :844
+              if (p5eps < round_) {
+                eps = 2.0 * round_ * (1.0 + fouru);
+                seg = SEG_CRASH;
+              } else {
+                S.g(1) = 1.0;
+                S.g(2) = 0.5;
+                S.sig(1) = 1.0;
+                if (fl & FL_START) {
+                  if (have_f) {
+                    seg = SEG_START_DONE;
+                  } else {  // f(x, yy) needed (:860)
+                    pc = PC_F1;
+                    seg = SEG_WAIT;
+                  }
+                } else {
+                  ifail = 0;
+                  seg = SEG_COEF;
+                }
+              }
+            }
+          }
+        }
+        if (seg == SEG_START_DONE) {
+          have_f = 0;
+          if (code) {  // :863 stop inside f: y, t untouched
+            stop = code;
+            seg = SEG_STOP;
+          } else {  // :865-885
+            double sm = 0.;
+#pragma unroll
+            for (int l = 0; l < NV; l++) {
+              F.lo[0][l] = f[l];
+              F.lo[1][l] = 0.0;
+              const double q = div(f[l], wt[l]);
+              sm += q * q;
+            }
+            const double total = sqrt(sm);
+            absh = fabs(h);
+            if (eps < 16.0 * total * h * h) absh = 0.25 * sqrt(eps / total);
+            h = copysign(fmax(absh, fouru * fabs(x)), h);
+            hold = 0.0;
+            k = 1;
+            kold = 0;
+            fl &= ~FL_START;
+            fl |= FL_PHASE1;
+            fl |= FL_NORND;
+            if (p5eps <= 100.0 * round_) {
+              fl &= ~FL_NORND;
+#pragma unroll
+              for (int l = 0; l < NV; l++) F.hi[15 - RR - LR - 1][l] = 0.0;
+            }
+            ifail = 0;
+            seg = SEG_COEF;
+          }
+        }
+        if (seg == SEG_COEF) {
+          // ---- coefficients + predictor (ode_RAYS.f90:892-1015) ----
+          const int kp1 = k + 1, kp2 = k + 2;
+          if (h != hold) ns = 0;
+          if (ns <= kold) ns = ns + 1;
+          const int nsp1 = ns + 1;
+          if (ns <= k) {
+            S.beta(ns) = 1.0;
+            S.alpha(ns) = 1.0 / (double)ns;
+            double temp1 = h * (double)ns;
+            S.sig(nsp1) = 1.0;
+            for (int i = nsp1; i <= k; i++) {
+              const double temp2 = S.psi(i - 1);
+              S.psi(i - 1) = temp1;
+              S.beta(i) = S.beta(i - 1) * S.psi(i - 1) / temp2;
+              temp1 = temp2 + h;
+              S.alpha(i) = h / temp1;
+              S.sig(i + 1) = (double)i * S.alpha(i) * S.sig(i);
+            }
+            S.psi(k) = temp1;
+            // w(1:12) is a work vector of this block only (ode_RAYS.f90:946-986): kept in registers,
+            // loops unrolled over the maximum order with per-lane bounds as predicates and a
+            // wave-uniform early exit.
+            double w[14];
+#pragma unroll
+            for (int iq = 0; iq < 14; iq++) w[iq] = 0.;
+            if (ns <= 1) {
+#pragma unroll
+              for (int iq = 1; iq <= 12; iq++) {
+                if (!__any(iq <= k)) break;
+                if (iq <= k) {
+                  const double c = 1.0 / (double)(iq * (iq + 1));
+                  S.v(iq) = c;
+                  w[iq] = c;
+                }
+              }
+            } else {
+              if (kold < k) {
+                S.v(k) = 1.0 / (double)(k * kp1);
+                for (int j = 1; j <= ns - 2; j++) {
+                  const int i = k - j;
+                  S.v(i) = S.v(i) - S.alpha(j + 1) * S.v(i + 1);
+                }
+              }
+              const double a_ns = S.alpha(ns);
+              const int lim = kp1 - ns;
+#pragma unroll
+              for (int iq = 1; iq <= 12; iq++) {  // ascending: v(iq+1) is still the old value
+                if (!__any(iq <= lim)) break;
+                if (iq <= lim) {
+                  const double c = S.v(iq) - a_ns * S.v(iq + 1);
+                  S.v(iq) = c;
+                  w[iq] = c;
+                }
+              }
+              S.g(nsp1) = w[1];
+            }
+            for (int i = ns + 2; i <= kp1; i++) {
+              const double a = S.alpha(i - 1);
+              const int lim = kp2 - i;
+#pragma unroll
+              for (int iq = 1; iq <= 12; iq++) {
+                if (!__any(iq <= lim)) break;
+                if (iq <= lim) w[iq] = w[iq] - a * w[iq + 1];
+              }
+              S.g(i) = w[1];
+            }
+          }
+          F.scale(nsp1, k, [&](int i) { return S.beta(i); });
+          {
+            double row[NV];
+            F.get(kp1, row);
+            F.set(kp2, row);  // phi(:,kp2) = phi(:,kp1)
+#pragma unroll
+            for (int l = 0; l < NV; l++) {
+              row[l] = 0.0;
+              pp[l] = 0.0;
+            }
+            F.set(kp1, row);  // phi(:,kp1) = 0
+          }
+          F.predict(k, [&](int i) { return S.g(i); }, pp);
+          if (!(fl & FL_NORND)) {
+#pragma unroll
+            for (int l = 0; l < NV; l++) {
+              const double tau = h * pp[l] - F.hi[15 - RR - LR - 1][l];
+              pp[l] = yy[l] + tau;
+              F.hi[16 - RR - LR - 1][l] = (pp[l] - yy[l]) - tau;
+            }
+          } else {
+#pragma unroll
+            for (int l = 0; l < NV; l++) pp[l] = yy[l] + h * pp[l];
+          }
+          xold = x;
+          x = x + h;
+          absh = fabs(h);
+          pc = PC_F2;
+          seg = SEG_WAIT;
+        }
+        if (seg == SEG_STOP) {
+          done = 1;
+#ifdef RAYS_SG_DEBUG
+          dbg[0] = (double)stop; dbg[1] = (double)pc; dbg[2] = (double)nostep; dbg[3] = (double)k;
+          dbg[4] = (double)code; dbg[5] = t; dbg[6] = tout;
+#endif
+          seg = SEG_WAIT;
         }
       }
 
@@ -605,15 +902,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
       }
     }
 
-    // ---- wave-level: flush staged points, refill finished lanes --------------------------------
-    if (done) {
-      stage.drain_own(A_hot, nbuf, first_pt);
-      nbuf = 0;
-    }
-    if (__any(nbuf == K)) {
-      stage.flush(A_hot, nbuf, first_pt);
-      nbuf = 0;
-    }
+    // ---- refill finished lanes ---------------------------------------------------------------
     if (done) {
       const TraceArgs& A = cold_args(A_hot);
       const unsigned nxt = atomicAdd(A.next_ray, 1u) + total_lanes;

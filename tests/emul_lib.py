@@ -14,16 +14,33 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _DIR = os.path.join(_ROOT, "tests", "hip_emul")
 _LIB = os.path.join(_DIR, "librays_emul.so")
 _lib = None
+# second build of the same sources with the SG kernel's fast storage tiers shrunk (rays_sg.hpp:
+# coefficient entries <= 2 and 2 + 1 phi rows instead of <= 8 and 4 + 4), so that ordinary rays
+# cross every tier boundary
+_TIERS_LIB = os.path.join(_DIR, "librays_emul_tiers.so")
+_TIERS_DEFS = ["-DRAYS_SG_TIER=2", "-DRAYS_SG_REG_ROWS=2", "-DRAYS_SG_LDS_ROWS=1"]
+_tiers_lib = None
 
 
-def build(sanitize: bool = False):
+def build(sanitize: bool = False, out: str = None, defs=()):
+    global _LIB
+    _LIB_SAVE = _LIB
+    if out is not None:
+        _LIB = out
+    try:
+        _build(sanitize, list(defs))
+    finally:
+        _LIB = _LIB_SAVE
+
+
+def _build(sanitize, defs):
     srcs = [os.path.join(_DIR, "emul_trace.cpp"), os.path.join(_DIR, "hip", "hip_runtime.h")]
     srcs += [os.path.join(_ROOT, "rays_amd", "csrc", f) for f in
              ("rays_device.hpp", "rays_trace.hpp", "rays_rk4.hpp", "rays_sg.hpp", "rays_dev_params.inc")]
     if os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs):
         return
     cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
-           "-w", "-I", _DIR, srcs[0], "-o", _LIB]
+           "-w", *defs, "-I", _DIR, srcs[0], "-o", _LIB]
     if sanitize:
         cmd[1:1] = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g"]
     subprocess.check_call(cmd)
@@ -37,11 +54,9 @@ def _set_zfun(fn):
     fn(f.ctypes.data_as(C.POINTER(C.c_double)), len(f), float(z["x_min"]), float(z["x_max"]))
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        build()
-        _lib = C.CDLL(_LIB)
+def _load(path):
+    if True:
+        _lib = C.CDLL(path)
         dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
         _lib.rays_emul_trace.restype = C.c_int
         _lib.rays_emul_trace.argtypes = [C.POINTER(RaysParams), C.c_int, dp, dp, dp, dp, ip, ip, dp, dp, dp]
@@ -51,15 +66,31 @@ def lib():
     return _lib
 
 
-def set_axisym_tables(tab: dict):
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = _load(_LIB)
+    return _lib
+
+
+def tiers_lib():
+    global _tiers_lib
+    if _tiers_lib is None:
+        build(out=_TIERS_LIB, defs=_TIERS_DEFS)
+        _tiers_lib = _load(_TIERS_LIB)
+    return _tiers_lib
+
+
+def set_axisym_tables(tab: dict, small_tiers: bool = False):
     t, keep = axisym_tables_struct(tab)
-    fn = lib().rays_emul_set_axisym_tables
+    fn = (tiers_lib() if small_tiers else lib()).rays_emul_set_axisym_tables
     fn.restype = C.c_int
     fn.argtypes = [C.POINTER(AxisymTables)]
     fn(C.byref(t))
 
 
-def trace(p: RaysParams, rvec0, rindex_vec0) -> dict:
+def trace(p: RaysParams, rvec0, rindex_vec0, small_tiers: bool = False) -> dict:
     rvec0 = np.ascontiguousarray(rvec0, dtype=np.float64)
     rindex_vec0 = np.ascontiguousarray(rindex_vec0, dtype=np.float64)
     nray, nv, npt = len(rvec0), p.nv, p.nstep_max + 1
@@ -69,7 +100,7 @@ def trace(p: RaysParams, rvec0, rindex_vec0) -> dict:
         end_ray_vec=np.zeros((nray, nv)), end_residuals=np.zeros(nray), max_residuals=np.zeros(nray))
     d = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
     i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
-    rc = lib().rays_emul_trace(C.byref(p), nray, d(rvec0), d(rindex_vec0), d(out["ray_vec"]),
+    rc = (tiers_lib() if small_tiers else lib()).rays_emul_trace(C.byref(p), nray, d(rvec0), d(rindex_vec0), d(out["ray_vec"]),
                                d(out["residual"]), i(out["npoints"]), i(out["stop_code"]),
                                d(out["end_ray_vec"]), d(out["end_residuals"]), d(out["max_residuals"]))
     if rc:

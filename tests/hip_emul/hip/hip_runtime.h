@@ -23,6 +23,8 @@ extern thread_local emul_dim3 threadIdx, blockIdx, blockDim, gridDim;
   namespace rays { double lds[1 << 16]; }
 
 inline int __any(int x) { return x; }
+inline unsigned long long __ballot(int x) { return x ? 1ull : 0ull; }
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 #define __builtin_amdgcn_readlane(v, r) ((r) == 0 ? (v) : 0)  /* only lane 0 exists */
 #define __builtin_amdgcn_wave_barrier() ((void)0)
 #define __builtin_amdgcn_fence(order, scope) ((void)0)

@@ -14,3 +14,19 @@ def test_kernel_source_on_host_equals_reference(name):
     g, nml, p = load_golden(name)
     out = emul_lib.trace(p, g["rvec0"], g["rindex_vec0"])
     assert_matches_golden(out, g, p, exact=True)
+
+
+@pytest.mark.parametrize("name", ["gold_solovev64_sg_cold", "gold_solovev64_sg_num", "gold_solovev64_damp_sg"])
+def test_sg_storage_tiers(name):
+    """The SG kernel keeps its coefficient vectors and divided differences in tiers (LDS / registers
+    for the low orders, private memory above; rays_sg.hpp).  Built with the fast tiers shrunk to
+    2 entries / 2 + 1 rows, every ray crosses every tier boundary; the result must not change.
+    The full 64-ray fan is used: a few of its rays reach order k = 10."""
+    g, nml, p = load_golden(name)
+    out = emul_lib.trace(p, g["rvec0"], g["rindex_vec0"], small_tiers=True)
+    assert_matches_golden(out, g, p, exact=True)
+    full_a = emul_lib.trace(p, g["rvec0_full"], g["rindex_vec0_full"])
+    full_b = emul_lib.trace(p, g["rvec0_full"], g["rindex_vec0_full"], small_tiers=True)
+    for k in ("ray_vec", "residual", "npoints", "stop_code", "end_ray_vec"):
+        np.testing.assert_array_equal(full_a[k], full_b[k])
+    np.testing.assert_array_equal(full_a["npoints"], g["npoints_full"])
