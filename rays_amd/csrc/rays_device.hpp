@@ -75,6 +75,44 @@ struct DevParams {
   double inv_rk, inv_rk2, inv_rmaj, inv_rmaj2, inv_psiB;
 };
 
+// ---------------------------------------------------------------------------------------------
+// hot_params(): the trace kernels' working copy of the parameter block.
+//
+// The block is ~170 doubles and a wave has ~100 SGPRs.  LLVM keeps what fits in SGPRs and, for the
+// rest, re-issues the scalar kernarg load inside the wave loop right where the value is used, i.e.
+// s_load + s_waitcnt lgkmcnt(0) back to back: eight such stalls per RHS evaluation, 21 % of the
+// RK4 kernel's wave time parked in s_waitcnt (rocprofv3 SQ_WAIT_ANY).  The per-species and
+// equilibrium constants the RHS reads on every evaluation are therefore moved into VECTOR
+// registers once per kernel (an opaque v_mov, so the compiler can neither keep them scalar nor
+// re-load them); the kernels run one wave per SIMD and leave the AGPR half of the register file
+// idle, which is where the allocator parks them.  Values are unchanged: bit-identical results.
+// ---------------------------------------------------------------------------------------------
+#ifdef RAYS_HOST_EMUL
+RAYS_DEV double in_vgpr(double x) { return x; }
+#else
+RAYS_DEV double in_vgpr(double x) {
+  double y;
+  asm volatile("v_mov_b64 %0, %1" : "=v"(y) : "s"(x));
+  return y;
+}
+#endif
+template <int EQ, int NS>
+RAYS_DEV void hot_params(const DevParams& P, DevParams& H) {
+  H = P;
+  constexpr int kHot = NS < 2 ? NS : 2;  // electrons + first ion species (more would spill VGPRs)
+#pragma unroll
+  for (int is = 0; is < kHot; is++) {
+    H.qs[is] = in_vgpr(P.qs[is]);
+    H.ms[is] = in_vgpr(P.ms[is]);
+    H.inv_ms[is] = in_vgpr(P.inv_ms[is]);
+    H.qs2[is] = in_vgpr(P.qs2[is]);
+    H.eps0ms[is] = in_vgpr(P.eps0ms[is]);
+    H.inv_eps0ms[is] = in_vgpr(P.inv_eps0ms[is]);
+    H.n0s[is] = in_vgpr(P.n0s[is]);
+    H.t0s[is] = in_vgpr(P.t0s[is]);
+  }
+}
+
 RAYS_DEV double sq(double x) { return x * x; }
 RAYS_DEV double pow4(double x) { return ((x * x) * x) * x; }  // flang lowers x**4 sequentially
 

@@ -19,7 +19,9 @@ namespace rays {
 
 template <int EQ, int NS, int DERIV, int NV, int K>
 __global__ void __launch_bounds__(256)
-rk4_trace_kernel(const DevParams P, const TraceArgs A_hot) {
+rk4_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
+  DevParams P;  // working copy: scalarised by the compiler, hot constants in vector registers
+  hot_params<EQ, NS>(P_kernarg, P);
   extern __shared__ double lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
