@@ -20,6 +20,9 @@
 
 namespace rays {
 
+#ifndef RAYS_FLUSH_G
+#define RAYS_FLUSH_G 4
+#endif
 constexpr int kWave = 64;
 constexpr int kRowStride = 65;  // doubles; 65 -> conflict-free b64 column reads at flush
 #ifdef RAYS_HOST_EMUL  // tests/hip_emul: one lane stands in for the whole wave
@@ -88,27 +91,49 @@ struct PointStage {
   }
 
   // All 64 lanes call this together.  nbuf = points this lane has staged, first_pt = global point
-  // index (ray*(nstep_max+1) + step) of its slot 0.
+  // index (ray*(nstep_max+1) + step) of its slot 0.  Four rays per pass: their LDS column reads are
+  // issued together and waited for once (with one ray per pass the wave sat out one LDS latency
+  // per ray, 64 times per flush).
   RAYS_DEV void flush(const TraceArgs& A_, int nbuf, long long first_pt) {
     const TraceArgs& A = cold_args(A_);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    constexpr int PER = NV + 1;                                      // doubles per point
+    constexpr int E = (K * PER + kFlushStride - 1) / kFlushStride;   // elements per lane and ray
+    constexpr int G = RAYS_FLUSH_G;                                  // rays per pass
 #pragma unroll 1
-    for (int r = 0; r < kWave; r++) {
-      const int n = __builtin_amdgcn_readlane(nbuf, r);
-      if (n == 0) continue;
-      const unsigned lo = __builtin_amdgcn_readlane((unsigned)(first_pt & 0xffffffffll), r);
-      const unsigned hi = __builtin_amdgcn_readlane((unsigned)((unsigned long long)first_pt >> 32), r);
-      const long long pt0 = (long long)(((unsigned long long)hi << 32) | lo);
-      const int total = n * (NV + 1);
-      for (int e = lane; e < total; e += kFlushStride) {
-        const int k = e / (NV + 1), c = e - k * (NV + 1);
-        const double val = base[e * kRowStride + r];
-        if (c < NV)
-          A.ray_vec[(pt0 + k) * NV + c] = val;
-        else
-          A.residual[pt0 + k] = val;
+    for (int r0 = 0; r0 < kWave; r0 += G) {
+      int total[G];
+      long long pt0[G];
+      double val[G][E];
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        const int r = r0 + j;
+        total[j] = __builtin_amdgcn_readlane(nbuf, r) * PER;
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)(first_pt & 0xffffffffll), r);
+        const unsigned hi = __builtin_amdgcn_readlane((unsigned)((unsigned long long)first_pt >> 32), r);
+        pt0[j] = (long long)(((unsigned long long)hi << 32) | lo);
       }
+#pragma unroll
+      for (int j = 0; j < G; j++)
+#pragma unroll
+        for (int q = 0; q < E; q++) {
+          const int e = lane + q * kFlushStride;
+          val[j][q] = e < total[j] ? base[e * kRowStride + r0 + j] : 0.;
+        }
+#pragma unroll
+      for (int j = 0; j < G; j++)
+#pragma unroll
+        for (int q = 0; q < E; q++) {
+          const int e = lane + q * kFlushStride;
+          if (e < total[j]) {
+            const int k = e / PER, c = e - k * PER;
+            if (c < NV)
+              A.ray_vec[(pt0[j] + k) * NV + c] = val[j][q];
+            else
+              A.residual[pt0[j] + k] = val[j][q];
+          }
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
