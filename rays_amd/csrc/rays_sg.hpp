@@ -9,10 +9,11 @@
 // MI355X design.  `step` calls the RHS at three places (start, predictor, corrector).  Run as
 // written, lanes that sit at different call sites would serialise three inlined copies of the
 // (expensive) RHS.  Here the integrator is a per-lane coroutine: every trip of the wave loop does
-// ONE convergent rhs_eval for all live lanes, then each lane runs the cheap continuation of its
-// own integrator (segments SEG_*) up to its next RHS request.  Divided differences phi(nv,16) and
-// the coefficient vectors are per-lane private arrays with data-dependent indices (order k is per
-// lane), i.e. scratch memory; the ODE vectors y, p, yp, wt are register-resident.
+// ONE convergent rhs_eval for the lanes of the phase being served, then each of them runs the
+// continuation of its own integrator (segments SEG_*, in pipeline order) up to its next RHS
+// request.  The integrator state that is indexed by the lane's order k lives in tiers (LDS /
+// registers for the low orders, private memory above: see "Per-lane integrator storage" below);
+// the ODE vectors y, p, wt are register-resident.
 //
 // Because SG_ode restarts the integrator on every output interval (fresh work arrays, iflag = 1),
 // the first RHS of `step` (start = true) is evaluated at the state check_save just saw, so it is
