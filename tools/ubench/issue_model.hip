@@ -1,4 +1,5 @@
-// Micro-benchmarks of single-wave-per-SIMD issue behaviour on gfx950 (developer tool, not product).
+// Micro-benchmarks of single-wave-per-SIMD issue behaviour on gfx950 (developer tool, not product;
+// results quoted in DESIGN.md 4.5).  hipcc -O3 -ffp-contract=off --offload-arch=gfx950 -o ub issue_model.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
