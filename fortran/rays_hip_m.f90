@@ -85,6 +85,20 @@
         type(rays_axisym_params_t) :: axisym
     end type rays_params_t
 
+    ! ray launchers on the device (rays_fan_t of rays_hip.h; SURVEY 8(f) f1)
+    integer(c_int32_t), parameter :: RAYS_RAY_INIT_SOLOVEV_NPHI_NTHETA = 0, &
+         & RAYS_RAY_INIT_AXISYM_R_Z_NPHI_NTHETA = 1, RAYS_RAY_INIT_SIMPLE_SLAB = 2
+    integer(c_int32_t), parameter :: RAYS_WAVE_PLUS = 0, RAYS_WAVE_MINUS = 1, RAYS_WAVE_FAST = 2, RAYS_WAVE_SLOW = 3
+    type, bind(C) :: rays_fan_t
+       integer(c_int32_t) :: model, wave_mode, k0_sign
+       integer(c_int32_t) :: n_r_launch, n_theta_launch, n_rindex_theta, n_rindex_phi
+       real(c_double) :: r_launch0, dr_launch, theta_launch0, dtheta_launch, z_launch0
+       real(c_double) :: rindex_theta0, delta_rindex_theta, rindex_phi0, delta_rindex_phi
+       integer(c_int32_t) :: n_x_launch, n_y_launch, n_z_launch, n_ky_launch, n_kz_launch, pad_
+       real(c_double) :: x_launch0, dx_launch, y_launch0, dy_launch, slab_z_launch0
+       real(c_double) :: rindex_y0, delta_rindex_y0, rindex_z0, delta_rindex_z0
+    end type rays_fan_t
+
     interface
 
        integer(c_int) function rays_hip_init(ngpu) bind(C, name='rays_hip_init')
@@ -138,6 +152,18 @@
           real(c_double), intent(inout) :: end_ray_vec(*), end_residuals(*), max_residuals(*)
           real(c_double), intent(out) :: elapsed_s
        end function rays_hip_trace
+
+       ! Replaces the serial launch loops of ray_init_m's launchers (solovev_ray_init_nphi_ntheta_m.f90:
+       ! 60-198 etc.): fills rvec0(3,nray_max), rindex_vec0(3,nray_max), ray_pwr_wt(nray_max), nray.
+       integer(c_int) function rays_hip_ray_init(p, fan, nray_max, rvec0, rindex_vec0, ray_pwr_wt, nray) &
+                    & bind(C, name='rays_hip_ray_init')
+          import :: c_int, c_int32_t, c_double, rays_params_t, rays_fan_t
+          type(rays_params_t), intent(in) :: p
+          type(rays_fan_t), intent(in) :: fan
+          integer(c_int), value :: nray_max
+          real(c_double), intent(inout) :: rvec0(3,*), rindex_vec0(3,*), ray_pwr_wt(*)
+          integer(c_int32_t), intent(out) :: nray
+       end function rays_hip_ray_init
 
     end interface
 

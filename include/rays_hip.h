@@ -247,6 +247,47 @@ int rays_hip_unpack_device(int nray, int nv, int nstep_max, const int32_t* d_npo
                            const double* d_packed_res, double* d_ray_vec, double* d_residual,
                            void* hip_stream);
 
+/* ---- ray initialisation on the device (the step before the hot path) -------
+ * Replaces the reference's serial launch loops
+ *   ray_init_solovev_nphi_ntheta            solovev_ray_init_nphi_ntheta_m.f90:60-198
+ *   ray_init_axisym_toroid_R_Z_nphi_ntheta  axisym_toroid_ray_init_R_Z_nphi_ntheta_m.f90:67-244
+ *   simple_slab_ray_init                    simple_slab_ray_init_m.f90:59-187
+ * (each: equilibrium at the launch point + cold dispersion root solve_n1_vs_n2_n3 per fan member,
+ * dispersion_solvers_m.f90:49-112; evanescent launches are dropped and the survivors numbered in
+ * loop order).  rays_fan_t mirrors the launcher's namelist
+ * (/solovev_ray_init_nphi_ktheta_list/, /axisym_toroid_ray_init_R_Z_nphi_ntheta_list/,
+ * /simple_slab_ray_init_list/) plus wave_mode / k0_sign of /rf_list/ (rf_m.f90:28-34). */
+enum { RAYS_RAY_INIT_SOLOVEV_NPHI_NTHETA = 0, RAYS_RAY_INIT_AXISYM_R_Z_NPHI_NTHETA = 1,
+       RAYS_RAY_INIT_SIMPLE_SLAB = 2 };
+enum { RAYS_WAVE_PLUS = 0, RAYS_WAVE_MINUS = 1, RAYS_WAVE_FAST = 2, RAYS_WAVE_SLOW = 3 };
+typedef struct rays_fan {
+  int32_t model;      /* RAYS_RAY_INIT_* ; must match rays_params_t.equilib_model */
+  int32_t wave_mode;  /* RAYS_WAVE_* */
+  int32_t k0_sign;    /* +1 | -1 */
+  /* solovev / axisym_toroid fans */
+  int32_t n_r_launch, n_theta_launch; /* solovev: minor radius x poloidal angle; axisym: n_R x n_Z */
+  int32_t n_rindex_theta, n_rindex_phi;
+  double r_launch0, dr_launch, theta_launch0, dtheta_launch; /* axisym: r_launch0 = R, z_launch0 = Z */
+  double z_launch0;
+  double rindex_theta0, delta_rindex_theta, rindex_phi0, delta_rindex_phi;
+  /* simple slab */
+  int32_t n_x_launch, n_y_launch, n_z_launch, n_ky_launch, n_kz_launch, pad_;
+  double x_launch0, dx_launch, y_launch0, dy_launch, slab_z_launch0;
+  double rindex_y0, delta_rindex_y0, rindex_z0, delta_rindex_z0;
+} rays_fan_t;
+int rays_hip_sizeof_fan(void);
+
+/* Host-pointer form: fills rvec0[nray_max][3], rindex_vec0[nray_max][3], ray_pwr_wt[nray_max]
+ * (= the reference's allocatable module arrays of ray_init_m.f90:47-53, C order) and *nray.
+ * Returns non-zero with the reference's message when the launcher would `stop 1`
+ * (improper number of rays, no successful initialisation). */
+int rays_hip_ray_init(const rays_params_t* p, const rays_fan_t* fan, int nray_max, double* rvec0,
+                      double* rindex_vec0, double* ray_pwr_wt, int32_t* nray);
+/* Device-pointer form (current device; d_* hold nray_max x 3 doubles): the fan never visits the
+ * host.  Synchronises `hip_stream` once to return *nray. */
+int rays_hip_ray_init_device(const rays_params_t* p, const rays_fan_t* fan, int nray_max,
+                             double* d_rvec0, double* d_rindex_vec0, int32_t* nray, void* hip_stream);
+
 /* Diagnostic entry used by the parity tests: evaluates equilibrium + deriv_cold + deriv_num +
  * eqn_ray + check_save at n states on the current device (host pointers; nv must be 7, nspec 1|2).
  * cold7/num7[n][7] = dddx(3) dddk(3) dddw; dvds[n][7]; resid[n]; codes[n][4] = equilibrium err,

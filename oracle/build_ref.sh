@@ -3,8 +3,9 @@
 # sources where they lie under /root/reference into binaries under oracle/_ref/.
 #
 #   oracle/_ref/rays_ref_dump   reference initialize + trace_rays + raw-binary dump (CPU)
-#   oracle/_ref/rays_hip_dropin reference host (initialize/ray_init/ray_results) with
-#                               trace_rays REPLACED by fortran/trace_rays_hip.f90 -> C-ABI
+#   oracle/_ref/rays_hip_dropin reference host (initialize/ray_results/...) with trace_rays
+#                               REPLACED by fortran/trace_rays_hip.f90 and the Solovev ray launcher
+#                               by fortran/solovev_ray_init_hip.f90 -> C-ABI
 #
 # Nothing from /root/reference is kept: sources are streamed through `sed` into a scratch
 # directory that is deleted before the script exits (objects, .mod files too); only the two
@@ -106,9 +107,18 @@ $FC $FFLAGS -o "$OUT/rays_ref_dump" ref_dump_driver.o ray_tracing_ref.o $LIBOBJS
 LIBHIP=$ROOT/rays_amd/lib/librays_hip.so
 if [ -f "$LIBHIP" ]; then
   $FC $FFLAGS -c "$ROOT/fortran/rays_hip_m.f90" -o rays_hip_m.o
+  $FC $FFLAGS -c "$ROOT/fortran/rays_hip_state_m.f90" -o rays_hip_state_m.o
   $FC $FFLAGS -c "$ROOT/fortran/trace_rays_hip.f90" -o trace_rays_hip.o
+  # the Solovev ray launcher replaced too: our module takes the place of the
+  # reference's solovev_ray_init_nphi_ntheta_m, and ray_init_m is recompiled against it
+  $FC $FFLAGS -c "$ROOT/fortran/solovev_ray_init_hip.f90" -o solovev_ray_init_hip.o
+  $FC $FFLAGS -c ray_init_m.f90 -o ray_init_m_dropin.o
+  DROPOBJS=$(for m in $MODS $EXTS; do
+      case "$m" in solovev_ray_init_nphi_ntheta_m) echo solovev_ray_init_hip.o;;
+                   ray_init_m) echo ray_init_m_dropin.o;;
+                   *) echo "$m.o";; esac; done)
   $FC $FFLAGS -c "$HERE/ref_dump_driver.f90" -o ref_dump_driver2.o
-  $FC $FFLAGS -o "$OUT/rays_hip_dropin" ref_dump_driver2.o trace_rays_hip.o rays_hip_m.o $LIBOBJS \
+  $FC $FFLAGS -o "$OUT/rays_hip_dropin" ref_dump_driver2.o trace_rays_hip.o rays_hip_state_m.o rays_hip_m.o $DROPOBJS \
      -L"$ROOT/rays_amd/lib" -lrays_hip -Wl,-rpath,'$ORIGIN/../../rays_amd/lib'
 else
   echo "build_ref: $LIBHIP not built yet -- skipping rays_hip_dropin"

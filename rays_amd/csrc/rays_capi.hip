@@ -16,6 +16,7 @@
 
 #include "../../include/rays_hip.h"
 #include "rays_launch.hpp"
+#include "rays_ray_init.hpp"
 
 namespace rays {
 #define RAYS_DECL_ENTRIES(s, e, d) \
@@ -36,6 +37,11 @@ RAYS_DECL_ENTRIES(1, 2, 1)
 hipError_t launch_pack(bool pack, int nray, int nv, int nstep_max, const int32_t* npoints,
                        const long long* offsets, double* ray_vec, double* residual, double* packed_vec,
                        double* packed_res, hipStream_t stream);
+struct FanArgs;
+hipError_t launch_ray_init(int eq_model, int ns, const DevParams& P, const FanArgs& F, int n_cand, double* cand,
+                           int* keep, int* block_count, int* offs, int* first_of_launch, double* rvec0,
+                           double* rindex_vec0, hipStream_t s);
+int ray_init_block();
 __global__ void probe_kernel(const DevParams P, int eq, int ns, int nv, int n, const double* v,
                              double* cold7, double* num7, double* dvds, double* resid, int* codes);
 }  // namespace rays
@@ -531,6 +537,108 @@ int rays_hip_unpack_device(int nray, int nv, int nstep_max, const int32_t* d_npo
 // Diagnostic entry (tests): evaluate the RHS pieces at n states on the current device.
 // v[n][nv] host; outputs host: cold7[n][7], num7[n][7], dvds[n][nv], resid[n], codes[n][4]
 // (codes: equilibrium err, eqn_ray stop code, check_save flag, check_save stop_ode).
+int rays_hip_sizeof_fan(void) { return (int)sizeof(rays_fan_t); }
+
+#include "rays_fan_setup.inc"
+
+static int ray_init_run(const rays_params_t* p, const rays_fan_t* fan, int nray_max, double* d_rvec0,
+                        double* d_rindex_vec0, int32_t* nray, hipStream_t stream,
+                        std::vector<int>* first_of_launch_host, int* per_r_launch) {
+  int rc = rays_hip_check_params(p);
+  if (rc) return rc;
+  if (!nray || !d_rvec0 || !d_rindex_vec0) return fail("rays_hip_ray_init: null pointer");
+  rays::FanArgs F;
+  std::vector<double> launch;
+  const char* why = "";
+  if (fan_setup(p, fan, nray_max, &F, &launch, per_r_launch, &why)) return fail(why);
+  const int n_cand = F.n_launch * F.n_a * F.n_b;
+  const int nb = (n_cand + rays::ray_init_block() - 1) / rays::ray_init_block();
+  rays::DevParams D = make_dev_params(*p);
+  if (p->equilib_model == RAYS_EQ_AXISYM) {
+    rc = get_axisym_device(&D);
+    if (rc) return rc;
+  }
+  double *d_launch = nullptr, *d_cand = nullptr;
+  int *d_keep = nullptr, *d_bc = nullptr, *d_offs = nullptr, *d_first = nullptr;
+  auto release = [&]() {
+    (void)hipFree(d_launch); (void)hipFree(d_cand); (void)hipFree(d_keep); (void)hipFree(d_bc);
+    (void)hipFree(d_offs); (void)hipFree(d_first);
+  };
+#define INIT_TRY(call)                                   \
+  do {                                                   \
+    hipError_t e_ = (call);                              \
+    if (e_ != hipSuccess) { release(); return hip_fail(e_, #call); } \
+  } while (0)
+  INIT_TRY(hipMalloc(&d_launch, sizeof(double) * launch.size()));
+  INIT_TRY(hipMalloc(&d_cand, sizeof(double) * 3 * (size_t)n_cand));
+  INIT_TRY(hipMalloc(&d_keep, sizeof(int) * (size_t)n_cand));
+  INIT_TRY(hipMalloc(&d_bc, sizeof(int) * (size_t)nb));
+  INIT_TRY(hipMalloc(&d_offs, sizeof(int) * (size_t)(nb + 1)));
+  INIT_TRY(hipMalloc(&d_first, sizeof(int) * (size_t)F.n_launch));
+  INIT_TRY(hipMemcpyAsync(d_launch, launch.data(), sizeof(double) * launch.size(), hipMemcpyHostToDevice, stream));
+  F.launch = d_launch;
+  INIT_TRY(rays::launch_ray_init(p->equilib_model, p->nspec + 1, D, F, n_cand, d_cand, d_keep, d_bc, d_offs,
+                                 d_first, d_rvec0, d_rindex_vec0, stream));
+  int total = 0;
+  INIT_TRY(hipMemcpyAsync(&total, d_offs + nb, sizeof(int), hipMemcpyDeviceToHost, stream));
+  if (first_of_launch_host) {
+    first_of_launch_host->resize(F.n_launch);
+    INIT_TRY(hipMemcpyAsync(first_of_launch_host->data(), d_first, sizeof(int) * F.n_launch, hipMemcpyDeviceToHost, stream));
+  }
+  INIT_TRY(hipStreamSynchronize(stream));
+#undef INIT_TRY
+  release();
+  *nray = total;
+  if (total == 0) return fail("No successful ray initializations");  // simple_slab_ray_init_m.f90:172
+  return 0;
+}
+
+int rays_hip_ray_init_device(const rays_params_t* p, const rays_fan_t* fan, int nray_max, double* d_rvec0,
+                             double* d_rindex_vec0, int32_t* nray, void* hip_stream) {
+  int per_r = 0;
+  return ray_init_run(p, fan, nray_max, d_rvec0, d_rindex_vec0, nray, (hipStream_t)hip_stream, nullptr, &per_r);
+}
+
+int rays_hip_ray_init(const rays_params_t* p, const rays_fan_t* fan, int nray_max, double* rvec0,
+                      double* rindex_vec0, double* ray_pwr_wt, int32_t* nray) {
+  if (!rvec0 || !rindex_vec0 || !nray) return fail("rays_hip_ray_init: null pointer");
+  if (nray_max <= 0) return fail("rays_hip_ray_init: nray_max <= 0");
+  double *d_r = nullptr, *d_n = nullptr;
+  HIP_TRY(hipMalloc(&d_r, sizeof(double) * 3 * (size_t)nray_max));
+  if (hipMalloc(&d_n, sizeof(double) * 3 * (size_t)nray_max) != hipSuccess) {
+    (void)hipFree(d_r);
+    return fail("rays_hip_ray_init: out of device memory");
+  }
+  std::vector<int> first;
+  int per_r = 0;
+  int rc = ray_init_run(p, fan, nray_max, d_r, d_n, nray, nullptr, &first, &per_r);
+  if (rc == 0) {
+    const size_t n = (size_t)*nray;
+    hipError_t e = hipMemcpy(rvec0, d_r, sizeof(double) * 3 * n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(rindex_vec0, d_n, sizeof(double) * 3 * n, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy (ray init results)");
+    if (rc == 0 && ray_pwr_wt) {
+      if (fan->model == RAYS_RAY_INIT_SIMPLE_SLAB) {  // :179,182: 1/nray, divided by nray once more
+        for (size_t i = 0; i < n; i++) ray_pwr_wt[i] = 1.0 / (double)n / (double)n;
+      } else if (fan->model == RAYS_RAY_INIT_AXISYM_R_Z_NPHI_NTHETA) {
+        for (size_t i = 0; i < n; i++) ray_pwr_wt[i] = 1.0 / (double)n;
+      } else {
+        // solovev_ray_init_nphi_ntheta_m.f90:196: only ray_pwr_wt(count) = 1. after each r-launch
+        // loop; the other entries are left unset by the reference (zero here)
+        for (size_t i = 0; i < n; i++) ray_pwr_wt[i] = 0.;
+        const int nl = (int)first.size();
+        for (int ir = 0; per_r > 0 && ir < nl / per_r; ir++) {
+          const int end = (ir + 1) * per_r < nl ? first[(ir + 1) * per_r] : (int)n;  // count after this r loop
+          if (end >= 1) ray_pwr_wt[end - 1] = 1.;
+        }
+      }
+    }
+  }
+  (void)hipFree(d_r);
+  (void)hipFree(d_n);
+  return rc;
+}
+
 int rays_hip_probe(const rays_params_t* p, int n, const double* v, double* cold7, double* num7,
                    double* dvds, double* resid, int32_t* codes) {
   int rc = rays_hip_check_params(p);

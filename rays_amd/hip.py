@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-from .params import AxisymTables, RaysParams, axisym_tables_struct
+from .params import AxisymTables, RaysFan, RaysParams, axisym_tables_struct
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RAYS_HIP_LIB") or os.path.join(_HERE, "lib", "librays_hip.so")
@@ -21,6 +21,7 @@ EXPORTED_SYMBOLS = (
     "rays_hip_last_error", "rays_hip_set_zfun_table", "rays_hip_set_axisym_tables",
     "rays_hip_stop_flag_text", "rays_hip_check_params", "rays_hip_trace", "rays_hip_trace_device",
     "rays_hip_kernel_name", "rays_hip_probe", "rays_hip_pack_device", "rays_hip_unpack_device",
+    "rays_hip_sizeof_fan", "rays_hip_ray_init", "rays_hip_ray_init_device",
 )
 
 _lib = None
@@ -71,6 +72,14 @@ def load():
     lib.rays_hip_unpack_device.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     lib.rays_hip_probe.restype = C.c_int
     lib.rays_hip_probe.argtypes = [pp, C.c_int, dp, dp, dp, dp, dp, ip]
+    lib.rays_hip_sizeof_fan.restype = C.c_int
+    if lib.rays_hip_sizeof_fan() != C.sizeof(RaysFan):
+        raise RaysHipError("rays_fan_t layout mismatch between librays_hip.so and rays_amd.params")
+    fp = C.POINTER(RaysFan)
+    lib.rays_hip_ray_init.restype = C.c_int
+    lib.rays_hip_ray_init.argtypes = [pp, fp, C.c_int, dp, dp, dp, ip]
+    lib.rays_hip_ray_init_device.restype = C.c_int
+    lib.rays_hip_ray_init_device.argtypes = [pp, fp, C.c_int, vp, vp, ip, vp]
     _lib = lib
     return lib
 
@@ -132,6 +141,27 @@ def _dp(a):
 
 def _ip(a):
     return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def ray_init_host(p: RaysParams, fan: RaysFan, nray_max: int):
+    """rays_hip_ray_init: the launch fan built on the GPU, returned as host arrays
+    (rvec0[nray][3], rindex_vec0[nray][3], ray_pwr_wt[nray]) -- the ray_init_m contract."""
+    n = int(nray_max)
+    rvec0, rindex_vec0, w = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros(n)
+    nray = C.c_int32(0)
+    _check(load().rays_hip_ray_init(C.byref(p), C.byref(fan), n, _dp(rvec0), _dp(rindex_vec0), _dp(w),
+                                    C.byref(nray)), "rays_hip_ray_init")
+    k = nray.value
+    return rvec0[:k].copy(), rindex_vec0[:k].copy(), w[:k].copy()
+
+
+def ray_init_device(p: RaysParams, fan: RaysFan, nray_max: int, d_rvec0: int, d_rindex_vec0: int,
+                    stream: int = 0) -> int:
+    """rays_hip_ray_init_device: fills the device arrays (nray_max x 3 doubles each), returns nray."""
+    nray = C.c_int32(0)
+    _check(load().rays_hip_ray_init_device(C.byref(p), C.byref(fan), int(nray_max), d_rvec0, d_rindex_vec0,
+                                           C.byref(nray), stream), "rays_hip_ray_init_device")
+    return nray.value
 
 
 def trace_host(p: RaysParams, rvec0, rindex_vec0, ngpu: int = 0) -> dict:

@@ -148,6 +148,29 @@ def axisym_tables_struct(tab: Dict[str, Any]):
     return t, keep
 
 
+RAY_INIT = {"solovev": 0, "axisym_toroid_ray_init_R_Z_nphi_ntheta": 1, "simple_slab": 2}
+WAVE_MODE = {"plus": 0, "minus": 1, "fast": 2, "slow": 3}
+
+
+class RaysFan(C.Structure):
+    """rays_fan_t of include/rays_hip.h: the ray launcher's namelist + wave_mode / k0_sign."""
+    _fields_ = [
+        ("model", C.c_int32), ("wave_mode", C.c_int32), ("k0_sign", C.c_int32),
+        ("n_r_launch", C.c_int32), ("n_theta_launch", C.c_int32),
+        ("n_rindex_theta", C.c_int32), ("n_rindex_phi", C.c_int32),
+        ("r_launch0", C.c_double), ("dr_launch", C.c_double),
+        ("theta_launch0", C.c_double), ("dtheta_launch", C.c_double), ("z_launch0", C.c_double),
+        ("rindex_theta0", C.c_double), ("delta_rindex_theta", C.c_double),
+        ("rindex_phi0", C.c_double), ("delta_rindex_phi", C.c_double),
+        ("n_x_launch", C.c_int32), ("n_y_launch", C.c_int32), ("n_z_launch", C.c_int32),
+        ("n_ky_launch", C.c_int32), ("n_kz_launch", C.c_int32), ("pad_", C.c_int32),
+        ("x_launch0", C.c_double), ("dx_launch", C.c_double), ("y_launch0", C.c_double),
+        ("dy_launch", C.c_double), ("slab_z_launch0", C.c_double),
+        ("rindex_y0", C.c_double), ("delta_rindex_y0", C.c_double),
+        ("rindex_z0", C.c_double), ("delta_rindex_z0", C.c_double),
+    ]
+
+
 class RaysParams(C.Structure):
     """ctypes image of ``rays_params_t`` (include/rays_hip.h)."""
 

@@ -22,7 +22,8 @@ from typing import Any, Dict, Tuple
 
 import numpy as np
 
-from .params import EQUILIB, RaysParams, SLAB_BY, SLAB_BZ, SLAB_N, SOLOVEV_N, ConfigError
+from .params import (EQUILIB, RAY_INIT, WAVE_MODE, ConfigError, RaysFan, RaysParams, SLAB_BY, SLAB_BZ, SLAB_N,
+                     SOLOVEV_N)
 
 
 # ---- launch-point equilibrium (host, scalar) ----------------------------------------------------
@@ -329,6 +330,7 @@ def ray_init_solovev_nphi_ntheta(p: RaysParams, nml: Dict[str, Dict[str, Any]]):
         raise ConfigError(f"solovev ray init: improper number of rays  nray={nray}")
     s = p.solovev
     rv, nv = [], []
+    marks = []  # ray count at the end of each r-launch loop (:196)
     for ir in range(n_r):
         for ith in range(n_th):
             theta = gf("theta_launch0") + ith * gf("dtheta_launch")
@@ -363,11 +365,17 @@ def ray_init_solovev_nphi_ntheta(p: RaysParams, nml: Dict[str, Dict[str, Any]]):
             cnt = int(keep.sum())
             rv.append(np.broadcast_to(rvec, (cnt, 3)))
             nv.append(rindex[keep] - npsi[keep][:, None] * psi_unit)
+        marks.append(sum(len(a) for a in rv))
     if not rv or sum(len(a) for a in rv) == 0:
         raise ConfigError("No successful ray initializations")
     rvec0 = np.ascontiguousarray(np.concatenate(rv, axis=0))
     rindex_vec0 = np.ascontiguousarray(np.concatenate(nv, axis=0))
-    ray_pwr_wt = np.zeros(len(rvec0))  # reference sets only ray_pwr_wt(count)=1. per launch (:196)
+    # the reference sets only ray_pwr_wt(count) = 1. after each r-launch loop (:196) and leaves the
+    # other entries of the freshly allocated array unset (zero here)
+    ray_pwr_wt = np.zeros(len(rvec0))
+    for c in marks:
+        if c >= 1:
+            ray_pwr_wt[c - 1] = 1.0
     return rvec0, rindex_vec0, ray_pwr_wt
 
 
@@ -430,3 +438,38 @@ def initialize_ray_init(p: RaysParams, nml: Dict[str, Dict[str, Any]], axisym_ta
             raise ConfigError("axisym_toroid ray init needs the host-built spline tables")
         return ray_init_axisym_toroid_R_Z_nphi_ntheta(p, nml, axisym_tables)
     raise ConfigError(f"initialize_ray_init: invalid ray_init_model = {model!r}")
+
+
+def fan_from_namelist(nml: Dict[str, Dict[str, Any]]) -> Tuple[RaysFan, int]:
+    """(rays_fan_t, nray_max) for the device-side launcher (rays_hip_ray_init): the launcher's
+    namelist group + wave_mode / k0_sign of /rf_list/, defaults as in the reference modules."""
+    model = str(nml.get("ray_init_list", {}).get("ray_init_model", "")).strip()
+    if model not in RAY_INIT:
+        raise ConfigError(f"initialize_ray_init: invalid ray_init_model = {model!r}")
+    rf = nml.get("rf_list", {})
+    wm = str(rf.get("wave_mode", "")).strip()
+    if wm not in WAVE_MODE:
+        raise ConfigError(f"solve_disp: improper wave_mode = {wm!r}")
+    f = RaysFan()
+    f.model, f.wave_mode, f.k0_sign = RAY_INIT[model], WAVE_MODE[wm], int(rf.get("k0_sign", 1))
+    nray_max = int(nml.get("ray_init_list", {}).get("nray_max", 0))
+    if model == "simple_slab":
+        g = nml.get("simple_slab_ray_init_list", {})
+        for k in ("n_x_launch", "n_y_launch", "n_z_launch"):
+            setattr(f, k, int(g.get(k, 1)))
+        for k in ("n_ky_launch", "n_kz_launch"):
+            setattr(f, k, int(g.get(k, 0)))
+        for k in ("x_launch0", "dx_launch", "y_launch0", "dy_launch", "rindex_y0", "delta_rindex_y0",
+                  "rindex_z0", "delta_rindex_z0"):
+            setattr(f, k, float(g.get(k, 0.0)))
+        f.slab_z_launch0 = float(g.get("z_launch0", 0.0))
+        return f, nray_max
+    g = nml.get("solovev_ray_init_nphi_ktheta_list" if model == "solovev"
+                else "axisym_toroid_ray_init_r_z_nphi_ntheta_list", {})
+    f.n_r_launch = int(g.get("n_r_launch", 1))
+    f.n_theta_launch = int(g.get("n_theta_launch" if model == "solovev" else "n_z_launch", 1))
+    f.n_rindex_theta, f.n_rindex_phi = int(g.get("n_rindex_theta", 1)), int(g.get("n_rindex_phi", 1))
+    for k in ("r_launch0", "dr_launch", "theta_launch0", "dtheta_launch", "z_launch0", "rindex_theta0",
+              "delta_rindex_theta", "rindex_phi0", "delta_rindex_phi"):
+        setattr(f, k, float(g.get(k, 0.0)))
+    return f, nray_max

@@ -8,7 +8,7 @@ import subprocess
 
 import numpy as np
 
-from rays_amd.params import AxisymTables, RaysParams, axisym_tables_struct
+from rays_amd.params import AxisymTables, RaysFan, RaysParams, axisym_tables_struct
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _DIR = os.path.join(_ROOT, "tests", "hip_emul")
@@ -36,7 +36,8 @@ def build(sanitize: bool = False, out: str = None, defs=()):
 def _build(sanitize, defs):
     srcs = [os.path.join(_DIR, "emul_trace.cpp"), os.path.join(_DIR, "hip", "hip_runtime.h")]
     srcs += [os.path.join(_ROOT, "rays_amd", "csrc", f) for f in
-             ("rays_device.hpp", "rays_trace.hpp", "rays_rk4.hpp", "rays_sg.hpp", "rays_dev_params.inc")]
+             ("rays_device.hpp", "rays_trace.hpp", "rays_rk4.hpp", "rays_sg.hpp", "rays_dev_params.inc",
+              "rays_ray_init.hpp", "rays_fan_setup.inc")]
     if os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs):
         return
     cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
@@ -106,3 +107,18 @@ def trace(p: RaysParams, rvec0, rindex_vec0, small_tiers: bool = False) -> dict:
     if rc:
         raise RuntimeError(f"rays_emul_trace rc={rc}")
     return out
+
+
+def ray_init(p: RaysParams, fan: RaysFan, nray_max: int):
+    """The device launcher's per-member function (rays_ray_init.hpp: fan_member) run on the host."""
+    n = int(nray_max)
+    rvec0, rindex_vec0 = np.zeros((n, 3)), np.zeros((n, 3))
+    nray = C.c_int32(0)
+    fn = lib().rays_emul_ray_init
+    fn.restype = C.c_int
+    dp = C.POINTER(C.c_double)
+    fn.argtypes = [C.POINTER(RaysParams), C.POINTER(RaysFan), C.c_int, dp, dp, C.POINTER(C.c_int32)]
+    rc = fn(C.byref(p), C.byref(fan), n, rvec0.ctypes.data_as(dp), rindex_vec0.ctypes.data_as(dp), C.byref(nray))
+    if rc:
+        raise RuntimeError(f"rays_emul_ray_init rc={rc}")
+    return rvec0[:nray.value].copy(), rindex_vec0[:nray.value].copy()

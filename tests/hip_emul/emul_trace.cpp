@@ -5,9 +5,11 @@
 RAYS_EMUL_DEFINE_GLOBALS
 #include "../../rays_amd/csrc/rays_rk4.hpp"
 #include "../../rays_amd/csrc/rays_sg.hpp"
+#include "../../rays_amd/csrc/rays_ray_init.hpp"
 
 // make_dev_params is host code in rays_capi.hip; reuse its text through a small include shim
 #include "emul_dev_params.inc"
+#include "../../rays_amd/csrc/rays_fan_setup.inc"
 
 template <int EQ, int DERIV>
 static void run(int solver, int nv, const rays::DevParams& D, const rays::TraceArgs& A) {
@@ -73,5 +75,43 @@ extern "C" int rays_emul_trace(const rays_params_t* p, int nray, const double* r
   RAYS_EMUL_CASE(4, 0) RAYS_EMUL_CASE(4, 1) RAYS_EMUL_CASE(5, 0) RAYS_EMUL_CASE(5, 1) RAYS_EMUL_CASE(6, 0) RAYS_EMUL_CASE(6, 1)
   return 4;
 #undef RAYS_EMUL_CASE
+  return 0;
+}
+
+// Ray initialisation (rays_ray_init.hpp: fan_member) run sequentially in the reference's loop order.
+template <int EQ>
+static bool emul_member(const rays::DevParams& D, const rays::FanArgs& F, const double* rvec, int ia, int ib, double* ri) {
+  return rays::fan_member<EQ, 2>(D, F, rvec, ia, ib, ri);
+}
+extern "C" int rays_emul_ray_init(const rays_params_t* p, const rays_fan_t* fan, int nray_max, double* rvec0,
+                                  double* rindex_vec0, int32_t* nray) {
+  if (p->nspec != 1) return 1;
+  rays::FanArgs F;
+  std::vector<double> launch;
+  int per_r = 0;
+  const char* why = "";
+  if (fan_setup(p, fan, nray_max, &F, &launch, &per_r, &why)) return 5;
+  F.launch = launch.data();
+  rays::DevParams D = make_dev_params(*p);
+  if (p->equilib_model == RAYS_EQ_AXISYM) {
+    if (g_axi[2].empty()) return 3;
+    D.a_nr = g_axi_n[0]; D.a_nz = g_axi_n[1]; D.a_n_rb = g_axi_n[2]; D.a_n_ne = g_axi_n[3]; D.a_n_te = g_axi_n[4]; D.a_n_ti = g_axi_n[5];
+    D.a_r_grid = g_axi[0].data(); D.a_z_grid = g_axi[1].data(); D.a_psi_fspl = g_axi[2].data();
+    D.a_rb_grid = g_axi[3].data(); D.a_rb_fspl = g_axi[4].data(); D.a_ne_grid = g_axi[5].data(); D.a_ne_fspl = g_axi[6].data();
+    D.a_te_grid = g_axi[7].data(); D.a_te_fspl = g_axi[8].data(); D.a_ti_grid = g_axi[9].data(); D.a_ti_fspl = g_axi[10].data();
+  }
+  int count = 0;
+  for (int il = 0; il < F.n_launch; il++)
+    for (int ia = 0; ia < F.n_a; ia++)
+      for (int ib = 0; ib < F.n_b; ib++) {
+        double ri[3];
+        const double* rv = &launch[3 * il];
+        const bool ok = p->equilib_model == 0 ? emul_member<0>(D, F, rv, ia, ib, ri)
+                        : p->equilib_model == 1 ? emul_member<1>(D, F, rv, ia, ib, ri) : emul_member<2>(D, F, rv, ia, ib, ri);
+        if (!ok) continue;
+        for (int i = 0; i < 3; i++) { rvec0[3 * count + i] = rv[i]; rindex_vec0[3 * count + i] = ri[i]; }
+        count++;
+      }
+  *nray = count;
   return 0;
 }

@@ -30,3 +30,16 @@ def test_sg_storage_tiers(name):
     for k in ("ray_vec", "residual", "npoints", "stop_code", "end_ray_vec"):
         np.testing.assert_array_equal(full_a[k], full_b[k])
     np.testing.assert_array_equal(full_a["npoints"], g["npoints_full"])
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_ray_init_source_on_host_equals_reference(name):
+    """Device-side ray initialisation: fan_member / solve_n1_vs_n2_n3 of
+    rays_ray_init.hpp compiled for the host reproduce the reference launcher's fan bit for bit
+    (rvec0, rindex_vec0 and the ray numbering after evanescent launches are dropped)."""
+    from rays_amd.ray_init import fan_from_namelist
+    g, nml, p = load_golden(name)
+    fan, nray_max = fan_from_namelist(nml)
+    r0, n0 = emul_lib.ray_init(p, fan, nray_max)
+    np.testing.assert_array_equal(r0, g["rvec0_full"])
+    np.testing.assert_array_equal(n0, g["rindex_vec0_full"])

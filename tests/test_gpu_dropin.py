@@ -1,5 +1,6 @@
 """Drop-in test: the REFERENCE host program (initialize / ray_init / ray_results_m, compiled from
-the reference sources) with `trace_rays` replaced by fortran/trace_rays_hip.f90 -> C ABI -> HIP,
+the reference sources) with `trace_rays` replaced by fortran/trace_rays_hip.f90 and the Solovev ray
+launcher by fortran/solovev_ray_init_hip.f90 -> C ABI -> HIP,
 against the unmodified reference binary on the same namelist.  Both binaries are built by
 oracle/build_ref.sh where /root/reference is available and travel to the GPU box prebuilt."""
 import os
@@ -41,6 +42,7 @@ def test_fortran_dropin_equals_reference_binary(cfg):
         hipr = _run(HIPBIN, cfg, os.path.join(d, "hip"))
     assert hipr["nray"] == ref["nray"]
     np.testing.assert_array_equal(hipr["rvec0"], ref["rvec0"])
+    np.testing.assert_array_equal(hipr["rindex_vec0"], ref["rindex_vec0"])  # Solovev cases: launched on the GPU
     np.testing.assert_array_equal(hipr["npoints"], ref["npoints"])
     assert hipr["stop_flag"] == ref["stop_flag"]          # the exact strings, leading blank included
     np.testing.assert_array_equal(hipr["ray_vec"][..., :7], ref["ray_vec"][..., :7])  # bit-identical trajectories

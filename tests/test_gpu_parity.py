@@ -102,3 +102,32 @@ def test_full_fan_matches_oracle():
     np.testing.assert_allclose(out["end_ray_vec"], ora["end_ray_vec"], rtol=1e-10, atol=0, equal_nan=True)
     np.testing.assert_allclose(out["end_residuals"], ora["end_residuals"], rtol=0, atol=1e-12)
     np.testing.assert_allclose(out["max_residuals"], ora["max_residuals"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_device_ray_init_matches_reference(name):
+    """rays_hip_ray_init: the fan built on the GPU equals the reference launcher's
+    rvec0 / rindex_vec0 bit for bit, in the same ray order."""
+    from rays_amd.ray_init import fan_from_namelist, initialize_ray_init
+    g, nml, p = load_golden(name)
+    fan, nray_max = fan_from_namelist(nml)
+    r0, n0, w = hip.ray_init_host(p, fan, nray_max)
+    np.testing.assert_array_equal(r0, g["rvec0_full"])
+    np.testing.assert_array_equal(n0, g["rindex_vec0_full"])
+    tab = {k[4:]: (float(g[k]) if g[k].ndim == 0 else g[k]) for k in g.files if k.startswith("axi_")}
+    _, _, w_host = initialize_ray_init(p, nml, tab or None)
+    np.testing.assert_array_equal(w, w_host)
+
+
+def test_device_ray_init_device_pointers_and_trace():
+    """Device-pointer form feeding the trace directly: the fan never visits the host."""
+    import torch
+    from rays_amd.ray_init import fan_from_namelist
+    g, nml, p = load_golden("cfg2_solovev1024_rk4")
+    fan, nray_max = fan_from_namelist(nml)
+    d_r = torch.zeros((nray_max, 3), dtype=torch.float64, device="cuda")
+    d_n = torch.zeros((nray_max, 3), dtype=torch.float64, device="cuda")
+    nray = hip.ray_init_device(p, fan, nray_max, d_r.data_ptr(), d_n.data_ptr())
+    assert nray == int(g["nray_full"])
+    np.testing.assert_array_equal(d_r[:nray].cpu().numpy(), g["rvec0_full"])
+    np.testing.assert_array_equal(d_n[:nray].cpu().numpy(), g["rindex_vec0_full"])
