@@ -288,6 +288,27 @@ int rays_hip_ray_init(const rays_params_t* p, const rays_fan_t* fan, int nray_ma
 int rays_hip_ray_init_device(const rays_params_t* p, const rays_fan_t* fan, int nray_max,
                              double* d_rvec0, double* d_rindex_vec0, int32_t* nray, void* hip_stream);
 
+/* ---- deposition profiles on the device (the step after the hot path) --------
+ * Replaces calculate_deposition_profiles / bin_a_ray (post_process_lib/deposition_profiles_m.f90:
+ * 228-292) with its evaluators Ptotal_axisym_psi / Ptotal_axisym_rho (:458-503) and the uniform
+ * grid binner (math_functions_lib/bin_to_uniform_grid_m.f90: binner_real), for
+ * equilib_model = 'axisym_toroid' runs with damping (nv >= 8), applied to the trajectory arrays
+ * where rays_hip_trace_device left them.
+ *   d_work[nray][n_bins]   per-ray binned power, the reference's work(n_bins, nray)
+ *   d_profile_out[n_bins]  = d_profile_in (or 0) + sum over rays IN RAY ORDER, the order of the
+ *                          reference's sum(work, 2): ranks that hold consecutive ray blocks chain
+ *                          their partial sums through d_profile_in and obtain the single-process
+ *                          result bit for bit (a few-KB exchange instead of the trajectory gather).
+ * Grid = [0, 1] in psiN or rho; the reference's default is n_bins = 100. */
+enum { RAYS_DEP_PTOTAL_PSI = 0, RAYS_DEP_PTOTAL_RHO = 1 };
+/* rho(psiN) spline of the eqdsk equilibrium (rho_profile of eqdsk_magnetics_spline_interp_m.f90:42,
+ * 190-193; fspl(4, n) on grid(n)); needed for RAYS_DEP_PTOTAL_RHO.  Copied. */
+int rays_hip_set_rho_table(const double* grid, const double* fspl, int n);
+int rays_hip_deposition_device(const rays_params_t* p, int which, int n_bins, int nray,
+                               const double* d_ray_vec, const int32_t* d_npoints,
+                               const double* d_initial_ray_power, double* d_work,
+                               const double* d_profile_in, double* d_profile_out, void* hip_stream);
+
 /* Diagnostic entry used by the parity tests: evaluates equilibrium + deriv_cold + deriv_num +
  * eqn_ray + check_save at n states on the current device (host pointers; nv must be 7, nspec 1|2).
  * cold7/num7[n][7] = dddx(3) dddk(3) dddw; dvds[n][7]; resid[n]; codes[n][4] = equilibrium err,

@@ -78,6 +78,12 @@ sed -i -e 's/& write_results_LD, write_results_NC, run_results/\& write_results_
 sed -i -e '/use multiple_mirror_eq_m/d' \
        -e "/case ('multiple_mirror')/,/multiple_mirror_eq/d" "$W/equilibrium_m.f90"
 
+# post_process_lib/deposition_profiles_m: the binning itself is plain Fortran; its
+# NetCDF writer (I/O only) is cut like P6
+s=$(grep -n '^ *subroutine write_deposition_profiles_NC' "$P/post_process_lib/deposition_profiles_m.f90" | cut -d: -f1)
+e=$(grep -n '^ *end subroutine check' "$P/post_process_lib/deposition_profiles_m.f90" | cut -d: -f1)
+sed -e "${s},${e}d" "$P/post_process_lib/deposition_profiles_m.f90" > "$W/deposition_profiles_m.f90"
+
 MODS="constants_m diagnostics_m
  bcspline ibc_ck v_spline bcspeval cspline cspeval splinck zonfind quick_cube_splines_m
  zfunctions_m quad_trapezoid_m bin_to_uniform_grid_m bisect_m monotonic_function_inversion
@@ -87,7 +93,7 @@ MODS="constants_m diagnostics_m
  temperature_spline_interp_m axisym_toroid_eq_m equilibrium_m suscep_m damping_m ode_m
  RK4_ode_m SG_ode_m dispersion_solvers_m simple_slab_ray_init_m solovev_ray_init_nphi_ntheta_m
  axisym_toroid_ray_init_R_Z_nphi_ntheta_m one_ray_init_XYZ_k_direction_m file_input_ray_init_m
- ray_init_m ray_results_m openmp_m"
+ ray_init_m ray_results_m openmp_m deposition_profiles_m"
 EXTS="check_save damp_fund_ECH deallocate deriv_cold deriv_num disp_solve_cold_n1sq_vs_n3
  disp_solve_cold_nsq_vs_theta disp_solve_n_vs_k_vec eqn_ray finalize_run get_unit_number
  initialize_ode_vector intialize ode_RAYS"

@@ -11,6 +11,9 @@
 !   RAYS_DUMP_PROBE  stride (in recorded points) for per-state probes of equilibrium,
 !                    deriv_cold, deriv_num, eqn_ray, check_save; 0/unset = no probes
 !   RAYS_DUMP_REPS   repeat trace_rays this many times for timing (default 1)
+!   RAYS_DUMP_DEPOSITION  output path for the deposition profiles of the run (reference
+!                    post_process_lib/deposition_profiles_m applied to the ray_results_m arrays;
+!                    slab and axisym_toroid only): per-ray binned arrays + summed profiles
 !
 ! When linked as oracle/_ref/rays_hip_dropin the same driver runs with trace_rays replaced by
 ! fortran/trace_rays_hip.f90 (the C-ABI drop-in), so both binaries write the same format.
@@ -20,13 +23,15 @@ program ref_dump_driver
     use rf_m, only : omgrf, k0, dispersion_resid_limit
     use ode_m, only : nv, ds, s_max, nstep_max, ode_stop
     use ray_init_m, only : nray, rvec0, rindex_vec0
-    use ray_results_m, only : ray_vec, residual, npoints, ray_stop_flag, end_ray_vec
+    use ray_results_m, only : ray_vec, residual, npoints, ray_stop_flag, end_ray_vec, initial_ray_power
+    use deposition_profiles_m, only : initialize_deposition_profiles, calculate_deposition_profiles, &
+         & bin_a_ray, profiles_1D, n_profiles
     use equilibrium_m, only : equilibrium, eq_point, equilib_model
     use solovev_eq_m, only : rmaj, kappa, bphi0, iota0, outer_bound, psiB
     use zfunctions_m, only : fsplRe, zf_nx => nx, x_grid_min, x_grid_max
     use axisym_toroid_eq_m, only : ax_rmin => box_rmin, ax_rmax => box_rmax, ax_zmin => box_zmin, &
          & ax_zmax => box_zmax, plasma_psi_limit
-    use eqdsk_magnetics_spline_interp_m, only : Psi_profile, T_profile
+    use eqdsk_magnetics_spline_interp_m, only : Psi_profile, T_profile, rho_profile
     use eqdsk_utilities_m, only : PSIBOUND
     use density_spline_interp_m, only : ne_profile_N
     use temperature_spline_interp_m, only : Te_profileN, Ti_profileN
@@ -35,7 +40,7 @@ program ref_dump_driver
 
     logical :: read_input = .true.
     character(len=256) :: fname, sval
-    integer :: u, u2, stat, probe_stride, reps, irep, iray, j, nprobe, is, n_ne, n_te, n_ti
+    integer :: u, u2, stat, probe_stride, reps, irep, iray, j, nprobe, is, n_ne, n_te, n_ti, ip
     real(kind=rkind) :: t0, t1, wall, resid, s
     real(kind=rkind), allocatable :: v(:), dvds(:)
     real(kind=rkind) :: dddx(3), dddk(3), dddw, ndx(3), ndk(3), ndw, nvec(3)
@@ -131,6 +136,33 @@ program ref_dump_driver
        write(u2) zf_nx
        write(u2) x_grid_min, x_grid_max
        write(u2) fsplRe
+       close(u2)
+    end if
+
+    call get_environment_variable('RAYS_DUMP_DEPOSITION', sval, status=stat)
+    if (stat == 0 .and. len_trim(sval) > 0 .and. nv >= 8 .and. &
+      & (trim(equilib_model) == 'axisym_toroid' .or. trim(equilib_model) == 'slab')) then
+       call initialize_deposition_profiles(.false.)     ! default n_bins (no post_process_rays.in)
+       open(newunit=u2, file=trim(sval), access='stream', form='unformatted', status='replace')
+       write(u2) n_profiles, profiles_1D(1)%n_bins, nray
+       write(u2) initial_ray_power(1:nray)
+       if (trim(equilib_model) == 'axisym_toroid') then   ! rho(psiN) spline of the eqdsk equilibrium
+          write(u2) rho_profile%nx
+          write(u2) rho_profile%x_grid, rho_profile%fspl
+       else
+          write(u2) 0
+       end if
+       do ip = 1, n_profiles          ! per-ray binned arrays, as calculate_deposition_profiles fills them
+          do iray = 1, nray
+             call bin_a_ray(profiles_1D(ip), iray)
+          end do
+          write(u2) profiles_1D(ip)%profile_name, profiles_1D(ip)%grid_min, profiles_1D(ip)%grid_max
+          write(u2) profiles_1D(ip)%work
+       end do
+       call calculate_deposition_profiles                ! the reference's own sums
+       do ip = 1, n_profiles
+          write(u2) profiles_1D(ip)%profile, profiles_1D(ip)%Q_sum
+       end do
        close(u2)
     end if
 

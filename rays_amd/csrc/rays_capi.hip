@@ -17,6 +17,7 @@
 #include "../../include/rays_hip.h"
 #include "rays_launch.hpp"
 #include "rays_ray_init.hpp"
+#include "rays_deposition.hpp"
 
 namespace rays {
 #define RAYS_DECL_ENTRIES(s, e, d) \
@@ -37,6 +38,8 @@ RAYS_DECL_ENTRIES(1, 2, 1)
 hipError_t launch_pack(bool pack, int nray, int nv, int nstep_max, const int32_t* npoints,
                        const long long* offsets, double* ray_vec, double* residual, double* packed_vec,
                        double* packed_res, hipStream_t stream);
+hipError_t launch_deposition(const DevParams& P, const DepArgs& D, const double* carry, double* profile,
+                             hipStream_t s);
 struct FanArgs;
 hipError_t launch_ray_init(int eq_model, int ns, const DevParams& P, const FanArgs& F, int n_cand, double* cand,
                            int* keep, int* block_count, int* offs, int* first_of_launch, double* rvec0,
@@ -537,6 +540,80 @@ int rays_hip_unpack_device(int nray, int nv, int nstep_max, const int32_t* d_npo
 // Diagnostic entry (tests): evaluate the RHS pieces at n states on the current device.
 // v[n][nv] host; outputs host: cold7[n][7], num7[n][7], dvds[n][nv], resid[n], codes[n][4]
 // (codes: equilibrium err, eqn_ray stop code, check_save flag, check_save stop_ode).
+// rho(psiN) spline table: host copy + lazily uploaded per-device copies (grid[n] then fspl[n][4])
+namespace {
+struct RhoTable {
+  std::vector<double> host;
+  int n = 0;
+  unsigned long long version = 0;
+};
+RhoTable g_rho;
+std::vector<ZfunDevice> g_rho_dev;
+int get_rho_device(const double** out, int* n) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_rho.n < 2) return fail("Ptotal_rho needs rays_hip_set_rho_table() first");
+  if ((int)g_rho_dev.size() <= dev) g_rho_dev.resize(dev + 1);
+  ZfunDevice& z = g_rho_dev[dev];
+  if (z.version != g_rho.version) {
+    if (z.ptr) (void)hipFree(z.ptr);
+    z.ptr = nullptr;
+    HIP_TRY(hipMalloc(&z.ptr, sizeof(double) * g_rho.host.size()));
+    HIP_TRY(hipMemcpy(z.ptr, g_rho.host.data(), sizeof(double) * g_rho.host.size(), hipMemcpyHostToDevice));
+    z.version = g_rho.version;
+  }
+  *out = z.ptr;
+  *n = g_rho.n;
+  return 0;
+}
+}  // namespace
+
+int rays_hip_set_rho_table(const double* grid, const double* fspl, int n) {
+  if (!grid || !fspl || n < 2) return fail("rays_hip_set_rho_table: bad table");
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_rho.host.assign(grid, grid + n);
+  g_rho.host.insert(g_rho.host.end(), fspl, fspl + 4 * (size_t)n);
+  g_rho.n = n;
+  g_rho.version++;
+  return 0;
+}
+
+int rays_hip_deposition_device(const rays_params_t* p, int which, int n_bins, int nray, const double* d_ray_vec,
+                               const int32_t* d_npoints, const double* d_initial_ray_power, double* d_work,
+                               const double* d_profile_in, double* d_profile_out, void* hip_stream) {
+  int rc = rays_hip_check_params(p);
+  if (rc) return rc;
+  if (p->equilib_model != RAYS_EQ_AXISYM)  // deposition_profiles_m.f90:141-222 knows slab and axisym_toroid
+    return fail("rays_hip_deposition: only equilib_model = 'axisym_toroid' profiles are on the device path");
+  if (p->nv < 8 || p->damping_model == RAYS_DAMP_NONE)
+    return fail("rays_hip_deposition: needs a run with damping (ray_vec(8) = absorbed power fraction)");
+  if (which != RAYS_DEP_PTOTAL_PSI && which != RAYS_DEP_PTOTAL_RHO)
+    return fail("initialize_deposition_profiles: unimplemented axisym_toroid profile");  // :208-212
+  if (n_bins < 1 || nray < 0) return fail("rays_hip_deposition: bad n_bins / nray");
+  if (!d_ray_vec || !d_npoints || !d_initial_ray_power || !d_work || !d_profile_out)
+    return fail("rays_hip_deposition: null device pointer");
+  rays::DevParams D = make_dev_params(*p);
+  rc = get_axisym_device(&D);
+  if (rc) return rc;
+  rays::DepArgs A;
+  A.which = which;
+  A.n_bins = n_bins; A.nray = nray; A.nv = p->nv; A.npt = p->nstep_max + 1;
+  A.grid_min = 0.0; A.grid_max = 1.0;  // :180-181
+  A.ray_vec = d_ray_vec; A.npoints = d_npoints; A.power = d_initial_ray_power; A.work = d_work;
+  A.rho_grid = nullptr; A.rho_fspl = nullptr; A.n_rho = 0;
+  if (which == RAYS_DEP_PTOTAL_RHO) {
+    const double* t = nullptr;
+    int n = 0;
+    rc = get_rho_device(&t, &n);
+    if (rc) return rc;
+    A.rho_grid = t; A.rho_fspl = t + n; A.n_rho = n;
+  }
+  hipError_t e = rays::launch_deposition(D, A, d_profile_in, d_profile_out, (hipStream_t)hip_stream);
+  if (e != hipSuccess) return hip_fail(e, "deposition kernels");
+  return 0;
+}
+
 int rays_hip_sizeof_fan(void) { return (int)sizeof(rays_fan_t); }
 
 #include "rays_fan_setup.inc"

@@ -22,6 +22,7 @@ EXPORTED_SYMBOLS = (
     "rays_hip_stop_flag_text", "rays_hip_check_params", "rays_hip_trace", "rays_hip_trace_device",
     "rays_hip_kernel_name", "rays_hip_probe", "rays_hip_pack_device", "rays_hip_unpack_device",
     "rays_hip_sizeof_fan", "rays_hip_ray_init", "rays_hip_ray_init_device",
+    "rays_hip_set_rho_table", "rays_hip_deposition_device",
 )
 
 _lib = None
@@ -80,6 +81,10 @@ def load():
     lib.rays_hip_ray_init.argtypes = [pp, fp, C.c_int, dp, dp, dp, ip]
     lib.rays_hip_ray_init_device.restype = C.c_int
     lib.rays_hip_ray_init_device.argtypes = [pp, fp, C.c_int, vp, vp, ip, vp]
+    lib.rays_hip_set_rho_table.restype = C.c_int
+    lib.rays_hip_set_rho_table.argtypes = [dp, dp, C.c_int]
+    lib.rays_hip_deposition_device.restype = C.c_int
+    lib.rays_hip_deposition_device.argtypes = [pp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     _lib = lib
     return lib
 
@@ -162,6 +167,24 @@ def ray_init_device(p: RaysParams, fan: RaysFan, nray_max: int, d_rvec0: int, d_
     _check(load().rays_hip_ray_init_device(C.byref(p), C.byref(fan), int(nray_max), d_rvec0, d_rindex_vec0,
                                            C.byref(nray), stream), "rays_hip_ray_init_device")
     return nray.value
+
+
+DEP_PROFILES = {"Ptotal_psi": 0, "Ptotal_rho": 1}
+
+
+def set_rho_table(grid, fspl):
+    """rho(psiN) spline of the eqdsk equilibrium (needed for the Ptotal_rho deposition profile)."""
+    grid = np.ascontiguousarray(grid, dtype=np.float64)
+    fspl = np.ascontiguousarray(fspl, dtype=np.float64)
+    _check(load().rays_hip_set_rho_table(_dp(grid), _dp(fspl), len(grid)), "rays_hip_set_rho_table")
+
+
+def deposition_device(p: RaysParams, which: str, n_bins: int, nray: int, d_ray_vec: int, d_npoints: int,
+                      d_power: int, d_work: int, d_profile_in, d_profile_out: int, stream: int = 0):
+    """rays_hip_deposition_device on device pointers (torch `.data_ptr()`s); d_profile_in may be None."""
+    _check(load().rays_hip_deposition_device(C.byref(p), DEP_PROFILES[which], int(n_bins), int(nray), d_ray_vec,
+                                             d_npoints, d_power, d_work, d_profile_in, d_profile_out, stream),
+           "rays_hip_deposition_device")
 
 
 def trace_host(p: RaysParams, rvec0, rindex_vec0, ngpu: int = 0) -> dict:

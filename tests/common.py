@@ -65,3 +65,12 @@ def assert_matches_golden(out, g, p, rel_tol=1e-10, resid_atol=1e-12, exact=Fals
     for r, n in enumerate(g["npoints"]):
         assert not out["ray_vec"][r, n:, :].any() and not out["residual"][r, n:].any()
     return worst
+
+
+def padded_full_trajectories(g, p):
+    """The full fan's trajectories of a fixture that carries them (dep_ray_vec_full), padded to the
+    reference layout [nray][nstep_max+1][nv]."""
+    rv = g["dep_ray_vec_full"]
+    out = np.zeros((rv.shape[0], p.nstep_max + 1, p.nv))
+    out[:, :rv.shape[1], :] = rv
+    return out

@@ -37,7 +37,7 @@ def _build(sanitize, defs):
     srcs = [os.path.join(_DIR, "emul_trace.cpp"), os.path.join(_DIR, "hip", "hip_runtime.h")]
     srcs += [os.path.join(_ROOT, "rays_amd", "csrc", f) for f in
              ("rays_device.hpp", "rays_trace.hpp", "rays_rk4.hpp", "rays_sg.hpp", "rays_dev_params.inc",
-              "rays_ray_init.hpp", "rays_fan_setup.inc")]
+              "rays_ray_init.hpp", "rays_fan_setup.inc", "rays_deposition.hpp")]
     if os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs):
         return
     cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
@@ -122,3 +122,25 @@ def ray_init(p: RaysParams, fan: RaysFan, nray_max: int):
     if rc:
         raise RuntimeError(f"rays_emul_ray_init rc={rc}")
     return rvec0[:nray.value].copy(), rindex_vec0[:nray.value].copy()
+
+
+def deposition(p: RaysParams, which: int, n_bins: int, ray_vec, npoints, power, rho_grid, rho_fspl):
+    """rays_deposition.hpp: deposit_ray + the ray-ordered profile sum, run on the host.
+    ray_vec[nray][nstep_max+1][nv] (padded reference layout)."""
+    nray = len(npoints)
+    ray_vec = np.ascontiguousarray(ray_vec, dtype=np.float64)
+    npoints = np.ascontiguousarray(npoints, dtype=np.int32)
+    power = np.ascontiguousarray(power, dtype=np.float64)
+    rho_grid = np.ascontiguousarray(rho_grid, dtype=np.float64)
+    rho_fspl = np.ascontiguousarray(rho_fspl, dtype=np.float64)
+    work, profile = np.zeros((nray, n_bins)), np.zeros(n_bins)
+    fn = lib().rays_emul_deposition
+    fn.restype = C.c_int
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    fn.argtypes = [C.POINTER(RaysParams), C.c_int, C.c_int, C.c_int, dp, ip, dp, dp, dp, C.c_int, dp, dp]
+    d = lambda a: a.ctypes.data_as(dp)
+    rc = fn(C.byref(p), which, n_bins, nray, d(ray_vec), npoints.ctypes.data_as(ip), d(power), d(rho_grid),
+            d(rho_fspl), len(rho_grid), d(work), d(profile))
+    if rc:
+        raise RuntimeError(f"rays_emul_deposition rc={rc}")
+    return work, profile

@@ -19,7 +19,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from tests.refdump import read_axisym_tables, read_dump  # noqa: E402
+from tests.refdump import read_axisym_tables, read_deposition, read_dump  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref", "rays_ref_dump")
 
@@ -55,11 +55,13 @@ def main():
                 if f.endswith(".geqdsk"):
                     shutil.copy(os.path.join(ROOT, "configs", f), d)
             env = dict(os.environ, RAYS_DUMP_FILE="dump.bin", RAYS_DUMP_PROBE=str(stride),
-                       RAYS_DUMP_AXISYM="axisym.bin")
+                       RAYS_DUMP_AXISYM="axisym.bin", RAYS_DUMP_DEPOSITION="dep.bin")
             subprocess.run([REF], cwd=d, env=env, check=True, stdout=subprocess.DEVNULL)
             ref = read_dump(os.path.join(d, "dump.bin"))
             axi = read_axisym_tables(os.path.join(d, "axisym.bin")) \
                 if os.path.exists(os.path.join(d, "axisym.bin")) else None
+            dep = read_deposition(os.path.join(d, "dep.bin")) \
+                if os.path.exists(os.path.join(d, "dep.bin")) else None
         idx = np.arange(ref["nray"]) if subset is None else np.array(subset)
         npts = ref["npoints"][idx]
         keep = int(npts.max())
@@ -85,6 +87,19 @@ def main():
             # the same tables next to the eqdsk file, for the Python host (RaysRun.from_namelist)
             np.savez_compressed(os.path.join(ROOT, "configs", "solovev_65x65.geqdsk.tables.npz"),
                                 **{k: np.asarray(v) for k, v in axi.items()})
+        if dep is not None:
+            # deposition profiles of the FULL fan + the full-fan trajectories they
+            # are binned from (v(1:3), v(8)) so the device binner can be checked without a re-trace
+            out["dep_n_bins"] = np.int32(dep["n_bins"])
+            out["dep_power"] = dep["power"]
+            out["dep_names"] = np.array(dep["names"])
+            out["dep_work"] = np.stack(dep["work"])          # [profile][nray][n_bins]
+            out["dep_profile"] = np.stack(dep["profile"])
+            out["dep_q_sum"] = np.array(dep["q_sum"])
+            if "rho_grid" in dep:
+                out["dep_rho_grid"], out["dep_rho_fspl"] = dep["rho_grid"], dep["rho_fspl"]
+            keep_full = int(ref["npoints"].max())
+            out["dep_ray_vec_full"] = ref["ray_vec"][:, :keep_full, :].copy()
         if stride and "probes" in ref:
             pr = ref["probes"]
             sel = np.linspace(0, len(pr) - 1, min(nprobe, len(pr))).astype(int)

@@ -74,3 +74,33 @@ def read_axisym_tables(path: str) -> dict:
             out[key + "_grid"], out[key + "_fspl"] = take(n), take(4 * n)
     assert off == len(b), (off, len(b))
     return out
+
+
+def read_deposition(path: str) -> dict:
+    """Deposition profiles written by ref_dump_driver.f90 (RAYS_DUMP_DEPOSITION): the reference's
+    post_process_lib/deposition_profiles_m applied to the run's ray_results_m arrays."""
+    b = open(path, "rb").read()
+    n_prof, n_bins, nray = (int(x) for x in np.frombuffer(b, dtype="<i4", count=3))
+    off = 12
+
+    def take(n):
+        nonlocal off
+        a = np.frombuffer(b, dtype="<f8", count=n, offset=off).copy()
+        off += 8 * n
+        return a
+
+    out = dict(n_bins=n_bins, power=take(nray), names=[], work=[], profile=[], q_sum=[])
+    n_rho = int(np.frombuffer(b, dtype="<i4", count=1, offset=off)[0])
+    off += 4
+    if n_rho:
+        out["rho_grid"], out["rho_fspl"] = take(n_rho), take(4 * n_rho)
+    for _ in range(n_prof):
+        out["names"].append(b[off:off + 20].decode().strip())
+        off += 20
+        take(2)  # grid_min, grid_max
+        out["work"].append(take(n_bins * nray).reshape(nray, n_bins))   # work(n_bins, nray)
+    for _ in range(n_prof):
+        out["profile"].append(take(n_bins))
+        out["q_sum"].append(float(take(1)[0]))
+    assert off == len(b), (off, len(b))
+    return out

@@ -43,3 +43,22 @@ def test_ray_init_source_on_host_equals_reference(name):
     r0, n0 = emul_lib.ray_init(p, fan, nray_max)
     np.testing.assert_array_equal(r0, g["rvec0_full"])
     np.testing.assert_array_equal(n0, g["rindex_vec0_full"])
+
+
+def test_deposition_source_on_host_equals_reference():
+    """Deposition profiles: deposit_ray (bin_a_ray + binner_real + the psi / rho
+    evaluators) and the ray-ordered sum reproduce the reference's work(n_bins, nray), profile and Q_sum
+    for Ptotal_psi and Ptotal_rho bit for bit."""
+    from tests.common import padded_full_trajectories
+    g, nml, p = load_golden("gold_axisym64_eqdsk_damp_rk4")
+    rv = padded_full_trajectories(g, p)
+    for which, name in enumerate(g["dep_names"]):
+        assert str(name) == ("Ptotal_psi", "Ptotal_rho")[which]
+        work, prof = emul_lib.deposition(p, which, int(g["dep_n_bins"]), rv, g["npoints_full"], g["dep_power"],
+                                         g["dep_rho_grid"], g["dep_rho_fspl"])
+        np.testing.assert_array_equal(work, g["dep_work"][which])
+        np.testing.assert_array_equal(prof, g["dep_profile"][which])
+        q = 0.0
+        for x in prof:
+            q = q + x
+        assert q == g["dep_q_sum"][which]

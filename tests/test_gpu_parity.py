@@ -131,3 +131,41 @@ def test_device_ray_init_device_pointers_and_trace():
     assert nray == int(g["nray_full"])
     np.testing.assert_array_equal(d_r[:nray].cpu().numpy(), g["rvec0_full"])
     np.testing.assert_array_equal(d_n[:nray].cpu().numpy(), g["rindex_vec0_full"])
+
+
+def test_device_deposition_profiles_match_reference():
+    """rays_hip_deposition_device on the trajectories of a device trace: work(n_bins, nray),
+    the profiles and Q_sum equal the reference post-processor's bit for bit; splitting the fan in two
+    blocks and chaining the partial sums (the multi-GPU exchange) gives the same bits."""
+    import torch
+    g, nml, p = load_golden("gold_axisym64_eqdsk_damp_rk4")
+    from rays_amd.trace import DeviceTrace
+    tr = DeviceTrace(p, g["rvec0_full"], g["rindex_vec0_full"])
+    tr.launch()
+    torch.cuda.synchronize()
+    nray, nb = tr.nray, int(g["dep_n_bins"])
+    np.testing.assert_array_equal(tr.npoints.cpu().numpy(), g["npoints_full"])
+    hip.set_rho_table(g["dep_rho_grid"], g["dep_rho_fspl"])
+    power = torch.as_tensor(g["dep_power"], device="cuda")
+    for which, name in enumerate(("Ptotal_psi", "Ptotal_rho")):
+        work = torch.zeros((nray, nb), dtype=torch.float64, device="cuda")
+        prof = torch.zeros(nb, dtype=torch.float64, device="cuda")
+        hip.deposition_device(p, name, nb, nray, tr.ray_vec.data_ptr(), tr.npoints.data_ptr(), power.data_ptr(),
+                              work.data_ptr(), None, prof.data_ptr())
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(work.cpu().numpy(), g["dep_work"][which])
+        np.testing.assert_array_equal(prof.cpu().numpy(), g["dep_profile"][which])
+        q = 0.0
+        for x in prof.cpu().numpy():
+            q = q + x
+        assert q == g["dep_q_sum"][which]
+        # two consecutive ray blocks, partial sums chained
+        h = nray // 2
+        part, tot = torch.zeros(nb, dtype=torch.float64, device="cuda"), torch.zeros(nb, dtype=torch.float64, device="cuda")
+        w2 = torch.zeros((nray, nb), dtype=torch.float64, device="cuda")
+        hip.deposition_device(p, name, nb, h, tr.ray_vec.data_ptr(), tr.npoints.data_ptr(), power.data_ptr(),
+                              w2.data_ptr(), None, part.data_ptr())
+        hip.deposition_device(p, name, nb, nray - h, tr.ray_vec[h:].data_ptr(), tr.npoints[h:].data_ptr(),
+                              power[h:].data_ptr(), w2[h:].data_ptr(), part.data_ptr(), tot.data_ptr())
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(tot.cpu().numpy(), g["dep_profile"][which])
