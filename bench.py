@@ -63,7 +63,8 @@ def build_fan(cfg_path, world, fan_scale=1, nstep_max=None):
         from rays_amd import hip
 
         hip.set_axisym_tables(tab)
-    r0, n0, _ = initialize_ray_init(p, nml, tab)
+    r0, n0, w = initialize_ray_init(p, nml, tab)
+    build_fan.ray_pwr_wt, build_fan.tables = w, tab   # for --exchange deposition
     return nml, p, r0, n0
 
 
@@ -136,6 +137,13 @@ def main():
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "cfg3b_solovev64k_rk4.in"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the trajectory gather (diagnostic)")
+    ap.add_argument("--exchange", choices=("gather", "deposition"), default="gather",
+                    help="what leaves the GPUs each pass: the packed trajectories, gathered to rank 0 "
+                         "(default, the BASELINE metric), or -- eqdsk + damping configs only -- the "
+                         "Ptotal(psiN) deposition profile, binned on the GPU and reduced over ranks in "
+                         "ray order (SURVEY 8(f) f2: n_bins doubles per rank instead of the trajectories)")
+    ap.add_argument("--exact-profile", action="store_true",
+                    help="--exchange deposition, N>1: ray-ordered chain over ranks (bit-identical to one process)")
     ap.add_argument("--verify-gather", action="store_true",
                     help="N>1 diagnostic: rank 0 re-traces the whole fan and checks the gathered arrays")
     ap.add_argument("--fan-scale", type=int, default=1,
@@ -195,6 +203,30 @@ def main():
             # pass i overlap the trace of pass i+1; barrier() below drains the last one
             tg.gather_async(tr.ray_vec, tr.residual, tr.npoints, tr.stop_code)
 
+    deposit = None
+    if args.exchange == "deposition":
+        from rays_amd.exchange import ProfileChain
+
+        gather = None
+        n_bins = 100  # deposition_profiles_m.f90:53 default_n_bins
+        power = torch.as_tensor(np.ascontiguousarray(build_fan.ray_pwr_wt[lo:hi]), dtype=torch.float64).to(dev)
+        work = torch.zeros((n_bins, hi - lo), dtype=torch.float64, device=dev)
+        chain = ProfileChain(n_bins, dev) if world > 1 else None
+        prof = torch.zeros(n_bins, dtype=torch.float64, device=dev)
+
+        def accumulate(carry, out):
+            hip.deposition_device(p, "Ptotal_psi", n_bins, hi - lo, tr.ray_vec.data_ptr(), tr.npoints.data_ptr(),
+                                  power.data_ptr(), work.data_ptr(), None if carry is None else carry.data_ptr(),
+                                  out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+
+        def deposit():
+            if chain is None:
+                accumulate(None, prof)
+            elif args.exact_profile:
+                chain.reduce(accumulate)            # bit-identical to one process; serialises the ranks
+            else:
+                chain.reduce_unordered(accumulate)  # per-rank ordered sums + one RCCL reduce
+
     def step(ev=None):
         if ev is not None:
             ev[0].record()
@@ -203,6 +235,8 @@ def main():
             ev[1].record()
         if gather is not None:
             gather()
+        if deposit is not None:
+            deposit()
 
     def barrier():
         if gather is not None:
@@ -269,7 +303,11 @@ def main():
                        "deriv": "cold" if p.ray_deriv == 0 else "numerical",
                        "kernel": hip.kernel_name(p),
                        "exchange": ("none" if world == 1 else
-                                    ("skipped" if args.no_gather else "packed send/recv to rank 0 (RCCL)"))},
+                                    ("skipped" if args.no_gather else "packed send/recv to rank 0 (RCCL)"))
+                       if args.exchange == "gather" else
+                       "deposition profile Ptotal(psiN), 100 bins, binned on the GPU"
+                       + ("" if world == 1 else (", ray-ordered chain over ranks (RCCL send/recv)" if args.exact_profile
+                                                 else ", per-rank sums + RCCL reduce to rank 0"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,

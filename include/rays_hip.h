@@ -294,12 +294,13 @@ int rays_hip_ray_init_device(const rays_params_t* p, const rays_fan_t* fan, int 
  * grid binner (math_functions_lib/bin_to_uniform_grid_m.f90: binner_real), for
  * equilib_model = 'axisym_toroid' runs with damping (nv >= 8), applied to the trajectory arrays
  * where rays_hip_trace_device left them.
- *   d_work[nray][n_bins]   per-ray binned power, the reference's work(n_bins, nray)
+ *   d_work[n_bins][nray]   per-ray binned power: the reference's work(n_bins, nray), stored bin-major
+ *                          (scratch of the call; transposed so that the reduction reads coalesce)
  *   d_profile_out[n_bins]  = d_profile_in (or 0) + sum over rays IN RAY ORDER, the order of the
  *                          reference's sum(work, 2): ranks that hold consecutive ray blocks chain
  *                          their partial sums through d_profile_in and obtain the single-process
  *                          result bit for bit (a few-KB exchange instead of the trajectory gather).
- * Grid = [0, 1] in psiN or rho; the reference's default is n_bins = 100. */
+ * Grid = [0, 1] in psiN or rho; the reference's default is n_bins = 100 (n_bins <= 320 here). */
 enum { RAYS_DEP_PTOTAL_PSI = 0, RAYS_DEP_PTOTAL_RHO = 1 };
 /* rho(psiN) spline of the eqdsk equilibrium (rho_profile of eqdsk_magnetics_spline_interp_m.f90:42,
  * 190-193; fspl(4, n) on grid(n)); needed for RAYS_DEP_PTOTAL_RHO.  Copied. */

@@ -7,10 +7,12 @@
 //   binner_real (bin_to_uniform_grid)           math_functions_lib/bin_to_uniform_grid_m.f90
 //   eqdsk_magnetics_spline_interp_psi / _rho    eqdsk_magnetics_spline_interp_m.f90:286-352
 //
-// One thread bins one ray (the binner walks the ray's points in order), into its own row of
-// work(n_bins, nray); the profile is then the sum over rays IN RAY ORDER, one thread per bin --
-// the order of the reference's sum(work, 2) -- optionally continued from another rank's partial
-// sums, so that the multi-GPU result is bit-identical to the single-process one.
+// One thread bins one ray (the binner walks the ray's points in order) into a row held in LDS and
+// writes it to work[bin][ray] (bin-major, so both this write and the reduction read coalesce).
+// The profile is then the sum over rays IN RAY ORDER -- the order of the reference's sum(work, 2);
+// floating-point addition is not associative -- one wave per bin: the lanes load 64 consecutive
+// rays at a time and the running sum walks through them with v_readlane.  It can be continued from
+// another rank's partial sums, so the multi-GPU result is bit-identical to the single-process one.
 #pragma once
 
 #include "rays_device.hpp"
@@ -27,7 +29,7 @@ struct DepArgs {
   const double* rho_grid;  // rho(psiN) spline (Ptotal_rho)
   const double* rho_fspl;
   int n_rho;
-  double* work;            // [nray][n_bins]
+  double* work;            // [n_bins][nray]
 };
 
 // grid value of a ray point: psiN or rho(psiN) at (x, y, z)
@@ -43,9 +45,16 @@ RAYS_DEV double dep_grid_value(const DevParams& P, const DepArgs& D, const doubl
   return rho;
 }
 
-// bin_a_ray + binner_real for ray `iray` into row[n_bins] (zeroed here, as the binner does)
-RAYS_DEV void deposit_ray(const DevParams& P, const DepArgs& D, int iray, double* row) {
+// bin_a_ray + binner_real for ray `iray` into row[b * stride], b = 0..n_bins-1 (zeroed here, as the
+// binner does)
+template <class RowPtr>
+RAYS_DEV void deposit_ray(const DevParams& P, const DepArgs& D, int iray, RowPtr row_base, int stride) {
   const int n_bins = D.n_bins;
+  struct Row {
+    RowPtr p;
+    int st;
+    RAYS_DEV auto& operator[](int b) const { return p[b * st]; }
+  } row{row_base, stride};
   for (int b = 0; b < n_bins; b++) row[b] = 0.;
   const int np = D.npoints[iray];
   const double* rv = D.ray_vec + (long long)iray * D.npt * D.nv;

@@ -12,6 +12,11 @@ Rays are independent, so the only exchange is the gather of each rank's trajecto
     of the padded global arrays.
   * no other collective exists on this path.
 
+When the consumer of the trajectories is the deposition-profile post-processor the
+trajectories need not leave their GPU at all: `ProfileChain` replaces the gather by a chain of
+n_bins-sized partial sums (rank r continues rank r-1's running sum over its own rays, in ray
+order), which reproduces the single-process profile bit for bit and moves a few KB per rank.
+
 pack / unpack are injected: on GPUs they are the HIP kernels of librays_hip.so
 (rays_hip_pack_device / rays_hip_unpack_device); the world_size-2 gloo test passes CPU stand-ins
 to exercise the protocol without a GPU.
@@ -184,3 +189,51 @@ class TrajectoryGather:
         """Synchronous form: returns with rank 0's global arrays complete (stream-ordered)."""
         self.gather_async(ray_vec, residual, npoints, stop_code)
         self.finish()
+
+
+class ProfileChain:
+    """Ray-ordered reduction of deposition profiles across ranks holding consecutive ray blocks.
+
+    The reference sums work(n_bins, nray) over rays sequentially (deposition_profiles_m.f90:246);
+    floating-point addition is not associative, so an all-reduce would change the bits.  Rank r
+    receives the running sums of ranks 0..r-1, lets `accumulate(carry_or_None, out)` add its own
+    rays in order (rays_hip_deposition_device with d_profile_in = carry), and passes the result on;
+    the last rank holds the total and sends it to rank 0.  Payload: n_bins doubles per hop."""
+
+    def __init__(self, n_bins: int, device, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.group = torch, dist, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.carry = torch.zeros(n_bins, dtype=torch.float64, device=device)
+        self.out = torch.zeros(n_bins, dtype=torch.float64, device=device)
+
+    def reduce_unordered(self, accumulate: Callable):
+        """Fast form: every rank sums its own rays (in order) and the partial profiles are combined
+        by one RCCL reduce to rank 0.  Differs from the single-process profile only by the
+        association of the per-rank partial sums (~1e-16 relative).  The ordered chain below costs
+        one dependent add per ray and bin across ALL ranks, i.e. it serialises the ranks."""
+        accumulate(None, self.out)
+        if self.world > 1:
+            self.dist.reduce(self.out, dst=0, op=self.dist.ReduceOp.SUM, group=self.group)
+        return self.out if self.rank == 0 else None
+
+    def reduce(self, accumulate: Callable):
+        """Bit-exact form.  Returns the total profile on rank 0 (None elsewhere)."""
+        d = self.dist
+        if self.rank > 0:
+            d.recv(self.carry, src=self.rank - 1, group=self.group)
+            accumulate(self.carry, self.out)
+        else:
+            accumulate(None, self.out)
+        if self.world == 1:
+            return self.out
+        if self.rank < self.world - 1:
+            d.send(self.out, dst=self.rank + 1, group=self.group)
+        else:
+            d.send(self.out, dst=0, group=self.group)
+        if self.rank == 0:
+            d.recv(self.out, src=self.world - 1, group=self.group)
+            return self.out
+        return None

@@ -88,6 +88,8 @@ class RaysRun:
         p = params_from_namelist(nml, tab)
         if tab is not None:
             hip.set_axisym_tables(tab)
+            if "rho_grid" in tab:
+                hip.set_rho_table(tab["rho_grid"], tab["rho_fspl"])
         r0, n0, w = initialize_ray_init(p, nml, tab)
         return cls(p, r0, n0, w, nml)
 

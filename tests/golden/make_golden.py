@@ -85,8 +85,10 @@ def main():
             for k, v in axi.items():
                 out["axi_" + k] = np.asarray(v)
             # the same tables next to the eqdsk file, for the Python host (RaysRun.from_namelist)
-            np.savez_compressed(os.path.join(ROOT, "configs", "solovev_65x65.geqdsk.tables.npz"),
-                                **{k: np.asarray(v) for k, v in axi.items()})
+            host_tabs = {k: np.asarray(v) for k, v in axi.items()}
+            if dep is not None and "rho_grid" in dep:   # rho(psiN) spline, for the Ptotal_rho profile
+                host_tabs.update(rho_grid=dep["rho_grid"], rho_fspl=dep["rho_fspl"])
+            np.savez_compressed(os.path.join(ROOT, "configs", "solovev_65x65.geqdsk.tables.npz"), **host_tabs)
         if dep is not None:
             # deposition profiles of the FULL fan + the full-fan trajectories they
             # are binned from (v(1:3), v(8)) so the device binner can be checked without a re-trace

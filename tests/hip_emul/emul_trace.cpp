@@ -131,7 +131,7 @@ extern "C" int rays_emul_deposition(const rays_params_t* p, int which, int n_bin
   A.grid_min = 0.; A.grid_max = 1.;
   A.ray_vec = ray_vec; A.npoints = npoints; A.power = power; A.work = work;
   A.rho_grid = rho_grid; A.rho_fspl = rho_fspl; A.n_rho = n_rho;
-  for (int r = 0; r < nray; r++) rays::deposit_ray(D, A, r, work + (size_t)r * n_bins);
+  for (int r = 0; r < nray; r++) rays::deposit_ray(D, A, r, work + (size_t)r * n_bins, 1);
   for (int b = 0; b < n_bins; b++) {
     double s = 0.;
     for (int r = 0; r < nray; r++) s = s + work[(size_t)r * n_bins + b];

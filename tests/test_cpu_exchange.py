@@ -58,6 +58,56 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _profile_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rays_amd.exchange import ProfileChain, shard_bounds
+        from tests import emul_lib
+        from tests.common import padded_full_trajectories
+
+        g, nml, p = load_golden("gold_axisym64_eqdsk_damp_rk4")
+        rv, nb = padded_full_trajectories(g, p), int(g["dep_n_bins"])
+        lo, hi = shard_bounds(rv.shape[0], world, rank)
+        work, _ = emul_lib.deposition(p, 0, nb, rv[lo:hi], g["npoints_full"][lo:hi], g["dep_power"][lo:hi],
+                                      g["dep_rho_grid"], g["dep_rho_fspl"])
+
+        def accumulate(carry, out):   # CPU stand-in of rays_hip_deposition_device's ordered sum
+            s = np.zeros(nb) if carry is None else carry.numpy().copy()
+            for r in range(work.shape[0]):
+                s = s + work[r]
+            out.copy_(torch.from_numpy(s))
+
+        chain = ProfileChain(nb, torch.device("cpu"))
+        tot = chain.reduce(accumulate)
+        exact = bool(np.array_equal(tot.numpy(), g["dep_profile"][0])) if rank == 0 else None
+        fast = chain.reduce_unordered(accumulate)   # per-rank sums + reduce: same to rounding
+        if rank == 0:
+            close = bool(np.allclose(fast.numpy(), g["dep_profile"][0], rtol=1e-12, atol=1e-300))
+            q.put(exact and close)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_profile_chain_gloo():
+    """Deposition profile over two ranks: chained partial sums == the reference's
+    single-process profile, bit for bit."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_profile_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(timeout=300)
+    assert all(pr.exitcode == 0 for pr in procs)
+    assert q.get(timeout=5) is True
+
+
 def test_shard_bounds():
     from rays_amd.exchange import shard_bounds
     for n, w in ((9, 2), (65536, 8), (3, 8), (0, 2)):

@@ -148,12 +148,12 @@ def test_device_deposition_profiles_match_reference():
     hip.set_rho_table(g["dep_rho_grid"], g["dep_rho_fspl"])
     power = torch.as_tensor(g["dep_power"], device="cuda")
     for which, name in enumerate(("Ptotal_psi", "Ptotal_rho")):
-        work = torch.zeros((nray, nb), dtype=torch.float64, device="cuda")
+        work = torch.zeros((nb, nray), dtype=torch.float64, device="cuda")   # bin-major
         prof = torch.zeros(nb, dtype=torch.float64, device="cuda")
         hip.deposition_device(p, name, nb, nray, tr.ray_vec.data_ptr(), tr.npoints.data_ptr(), power.data_ptr(),
                               work.data_ptr(), None, prof.data_ptr())
         torch.cuda.synchronize()
-        np.testing.assert_array_equal(work.cpu().numpy(), g["dep_work"][which])
+        np.testing.assert_array_equal(work.cpu().numpy().T, g["dep_work"][which])
         np.testing.assert_array_equal(prof.cpu().numpy(), g["dep_profile"][which])
         q = 0.0
         for x in prof.cpu().numpy():
@@ -162,10 +162,10 @@ def test_device_deposition_profiles_match_reference():
         # two consecutive ray blocks, partial sums chained
         h = nray // 2
         part, tot = torch.zeros(nb, dtype=torch.float64, device="cuda"), torch.zeros(nb, dtype=torch.float64, device="cuda")
-        w2 = torch.zeros((nray, nb), dtype=torch.float64, device="cuda")
+        w2 = torch.zeros((nb, nray), dtype=torch.float64, device="cuda")
         hip.deposition_device(p, name, nb, h, tr.ray_vec.data_ptr(), tr.npoints.data_ptr(), power.data_ptr(),
                               w2.data_ptr(), None, part.data_ptr())
         hip.deposition_device(p, name, nb, nray - h, tr.ray_vec[h:].data_ptr(), tr.npoints[h:].data_ptr(),
-                              power[h:].data_ptr(), w2[h:].data_ptr(), part.data_ptr(), tot.data_ptr())
+                              power[h:].data_ptr(), w2.data_ptr(), part.data_ptr(), tot.data_ptr())
         torch.cuda.synchronize()
         np.testing.assert_array_equal(tot.cpu().numpy(), g["dep_profile"][which])
