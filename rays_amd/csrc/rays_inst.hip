@@ -35,8 +35,7 @@ constexpr int DERIV = RAYS_INST_DERIV;
 template <int NS, int NV>
 hipError_t launch_one(const DevParams& P, const TraceArgs& A, hipStream_t stream, int* grid_blocks) {
 #if RAYS_INST_SOLVER == 0
-  constexpr size_t lds = (size_t)(kBlock / kWave) * PointStage<NV, stage_k<NV>()>::kDoublesPerWave * sizeof(double);
-  return launch_persistent(rk4_trace_kernel<EQ, NS, DERIV, NV, stage_k<NV>()>, lds, P, A, stream, grid_blocks);
+  return launch_persistent(rk4_trace_kernel<EQ, NS, DERIV, NV>, 0, P, A, stream, grid_blocks);
 #else
   constexpr size_t lds = (size_t)(kBlock / kWave) * SgLds<NV>::kDoublesPerWave * sizeof(double);
   return launch_persistent(sg_trace_kernel<EQ, NS, DERIV, NV>, lds, P, A, stream, grid_blocks);

@@ -22,10 +22,6 @@ struct KernelEntry {
   hipError_t (*launch)(const DevParams&, const TraceArgs&, hipStream_t stream, int* grid_blocks);
 };
 
-// Points staged in LDS per lane before a coalesced flush: 8 for nv = 7|8 (33|37 KB/wave), 4 for
-// nv = 12|13 (27|29 KB/wave), so a 4-wave workgroup stays inside the CU's 160 KB.
-template <int NV>
-constexpr int stage_k() { return NV <= 8 ? 8 : 4; }
 constexpr int kBlock = 256;
 
 template <typename Kernel>

@@ -11,23 +11,23 @@
 //                 f1 = eqn_ray(w) (same equilibrium + dispersion derivatives, evaluated once)
 // A new ray starts in stage 3 with w = v0 (`first`), which is exactly the reference's initial
 // check_save call (ray_tracing.f90:100) and also yields the first step's f1.
+//
+// Recorded points are written by their own lane, eight 8-byte stores per step (record_point).  An
+// earlier version staged 8 points per lane in LDS and flushed them as 512-byte runs per ray; the
+// kernel is bound by instruction issue, not by HBM, and the flush's ~500 issue
+// slots per step cost 12 % of the 64k-fan pass against 14 for the direct stores (measured:
+// 5.05 -> 4.49 ms; HBM write traffic per launch in profiles/).
 #pragma once
 
 #include "rays_trace.hpp"
 
 namespace rays {
 
-template <int EQ, int NS, int DERIV, int NV, int K>
+template <int EQ, int NS, int DERIV, int NV>
 __global__ void __launch_bounds__(256)
 rk4_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
   DevParams P;  // working copy: scalarised by the compiler, hot constants in vector registers
   hot_params<EQ, NS>(P_kernarg, P);
-  extern __shared__ double lds[];
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x / kWave;
-  PointStage<NV, K> stage;
-  stage.base = lds + wave * PointStage<NV, K>::kDoublesPerWave;
-  stage.lane = lane;
 
   const unsigned total_lanes = gridDim.x * blockDim.x;
   const long long npt = (long long)P.nstep_max + 1;
@@ -42,8 +42,6 @@ rk4_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
   double s = 0., sout = 0., dsl = 0.;
   double v[NV], w[NV], acc[NV];
   double last_resid = 0., prev_resid = 0., maxr = -1.7976931348623157e308;
-  int nbuf = 0;            // points staged in LDS since the last flush
-  long long first_pt = 0;  // global point index of staged slot 0
 #pragma unroll
   for (int i = 0; i < NV; i++) v[i] = w[i] = acc[i] = 0.;
 
@@ -106,9 +104,7 @@ rk4_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
         // stage 3: w is the new state; check_save decides whether the step is recorded
         if (first) {
           // ray_tracing.f90:92-112: point 1 = initial state, residual(1) = 0
-          if (nbuf == 0) first_pt = (long long)ray * npt;
-          stage.put(nbuf, v, 0.);
-          nbuf++;
+          record_point<NV>(A_hot, (long long)ray * npt, v, 0.);
           if (cs_stop) {  // ray did not start: npoints = 1, summary fields stay zero
             const TraceArgs& A = cold_args(A_hot);
             A.npoints[ray] = 1;
@@ -131,9 +127,7 @@ rk4_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
             done = 1;
           } else {  // :237-243
             nstep = nstep + 1;
-            if (nbuf == 0) first_pt = (long long)ray * npt + nstep;
-            stage.put(nbuf, v, resid);
-            nbuf++;
+            record_point<NV>(A_hot, (long long)ray * npt + nstep, v, resid);
             if (fabs(last_resid) > maxr) maxr = fabs(last_resid);
             prev_resid = last_resid;
             last_resid = resid;
@@ -176,17 +170,7 @@ rk4_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
       }
     }
 
-    // ---- wave-level: flush staged points, refill finished lanes --------------------------------
-    if (done) {
-      // a finished lane's points must leave LDS before the lane is re-used for another ray:
-      // it drains its own column (once per ray; the coalesced path is the wave flush below)
-      stage.drain_own(A_hot, nbuf, first_pt);
-      nbuf = 0;
-    }
-    if (__any(nbuf == K)) {
-      stage.flush(A_hot, nbuf, first_pt);
-      nbuf = 0;
-    }
+    // ---- refill finished lanes ---------------------------------------------------------------
     if (done) {
       const TraceArgs& A = cold_args(A_hot);
       const unsigned nxt = atomicAdd(A.next_ray, 1u) + total_lanes;

@@ -45,14 +45,6 @@ enum : int {
   SEG_STOP         // ray finished with code `stop`
 };
 
-// One recorded trajectory point, written by its own lane: ray_vec(:, pt) and residual(pt).
-template <int NV>
-RAYS_DEV void record_point(const TraceArgs& A, long long pt, const double v[NV], double resid) {
-#pragma unroll
-  for (int c = 0; c < NV; c++) A.ray_vec[pt * NV + c] = v[c];
-  A.residual[pt] = resid;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Per-lane integrator storage.
 //

@@ -16,10 +16,10 @@ template <int EQ, int DERIV>
 static void run(int solver, int nv, const rays::DevParams& D, const rays::TraceArgs& A) {
   threadIdx.x = 0; blockIdx.x = 0; blockDim.x = 1; gridDim.x = 1;
   if (nv == 7) {
-    if (solver == 0) rays::rk4_trace_kernel<EQ, 2, DERIV, 7, 8>(D, A);
+    if (solver == 0) rays::rk4_trace_kernel<EQ, 2, DERIV, 7>(D, A);
     else rays::sg_trace_kernel<EQ, 2, DERIV, 7>(D, A);
   } else {
-    if (solver == 0) rays::rk4_trace_kernel<EQ, 2, DERIV, 8, 8>(D, A);
+    if (solver == 0) rays::rk4_trace_kernel<EQ, 2, DERIV, 8>(D, A);
     else rays::sg_trace_kernel<EQ, 2, DERIV, 8>(D, A);
   }
 }
