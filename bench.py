@@ -311,7 +311,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "FP64-VALU/latency bound path: 64 B written per ~3 kflop step (DESIGN.md)"},
+                         "note": "bound by instruction issue of one wave per SIMD (~3.6k instructions per 64-B step), not by HBM: DESIGN.md 4.5"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config)

@@ -1,7 +1,7 @@
 """CPU tier: the PRODUCT kernel source (rays_amd/csrc/rays_rk4.hpp, rays_sg.hpp, rays_device.hpp)
 compiled for the host with a one-lane HIP emulation (tests/hip_emul) and compared with the
 reference golden vectors bit for bit.  This covers the integrator state machines, stop logic,
-LDS staging/flush indexing and the summary fields without a GPU."""
+the SG storage tiers, point recording and the summary fields without a GPU."""
 import numpy as np
 import pytest
 
