@@ -63,6 +63,18 @@ const KernelEntry kEntries[] = {
 };
 }  // namespace
 
+#if defined(RAYS_SG_PROFILE) && RAYS_INST_SOLVER == 1
+// developer builds only: per-section wave clocks of this group's SG kernels
+extern "C" int RAYS_CAT(rays_debug_sg_profile, RAYS_INST_SOLVER, RAYS_INST_EQ, RAYS_INST_DERIV, RAYS_INST_UE)(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sg_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_sg_prof), z, sizeof z) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
+
 const KernelEntry* RAYS_CAT(rays_entries, RAYS_INST_SOLVER, RAYS_INST_EQ, RAYS_INST_DERIV, RAYS_INST_UE)(int* n) {
   *n = (int)(sizeof(kEntries) / sizeof(kEntries[0]));
   return kEntries;

@@ -24,6 +24,26 @@
 
 namespace rays {
 
+// Developer build (-DRAYS_SG_PROFILE): wave-clock spent per section of the wave loop, summed over all
+// waves into g_sg_prof (read back by rays_hip_debug_sg_profile).  Not compiled into the product.
+#ifdef RAYS_SG_PROFILE
+__device__ unsigned long long g_sg_prof[16];
+#define SG_PROF_DECL unsigned long long prof_t = clock64(), prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define SG_PROF(slot)                              \
+  do {                                             \
+    const unsigned long long now_ = clock64();     \
+    prof_acc[slot] += now_ - prof_t;               \
+    prof_t = now_;                                 \
+  } while (0)
+#define SG_PROF_FLUSH                                                          \
+  if ((threadIdx.x & 63) == 0)                                                 \
+    for (int i_ = 0; i_ < 16; i_++) atomicAdd(&g_sg_prof[i_], prof_acc[i_]);
+#else
+#define SG_PROF_DECL
+#define SG_PROF(slot) ((void)0)
+#define SG_PROF_FLUSH
+#endif
+
 enum : int {
   PC_CHECK = 0,  // rhs at the recorded state: check_save + start-of-interval f
   PC_F1 = 1,     // start f after a crash/restart inside an interval (ode_RAYS.f90:860)
@@ -371,7 +391,9 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
 #pragma unroll
   for (int i = 0; i < NV; i++) vst[i] = yy[i] = pp[i] = wt[i].d = wt[i].rc = 0.;
 
+  SG_PROF_DECL
   while (__any(alive)) {
+    SG_PROF(0);  // loop overhead, refill
     if (need_init) {  // ray_tracing.f90:77-93, SG_ode_m.f90:73-85
       const TraceArgs& A = cold_args(A_hot);  // rays_trace.hpp
       initialize_ode_vector<EQ, NS, NV>(P, A.rvec0 + 3ll * ray, A.rindex_vec0 + 3ll * ray, vst);
@@ -407,7 +429,9 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
     double win[NV];
 #pragma unroll
     for (int l = 0; l < NV; l++) win[l] = pc == PC_F2 ? pp[l] : (pc == PC_CHECK ? vst[l] : yy[l]);
+    SG_PROF(1);  // init + phase vote
     if (act) rhs_eval<EQ, NS, DERIV, NV>(P, win, pc == PC_CHECK, resid, cs_flag, cs_stop, code, f);
+    SG_PROF(2);  // RHS
 
     // ---- per-lane continuation -------------------------------------------------------------------
     int stop = 0;
@@ -474,6 +498,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
       // Continuation segments in pipeline order: a lane falls through AFTER_F3 -> DE_TOP -> COEF (or
       // CHECK -> DE_BEGIN -> DE_TOP -> START_DONE -> COEF) in ONE pass, so each segment's code runs
       // at most once per trip for the whole wave; only the rare DE_TOP -> CRASH edge goes round again.
+      SG_PROF(3);  // CHECK bookkeeping
       while (seg != SEG_WAIT) {
         if (seg == SEG_AFTER_F2) {
           if (code) {  // :1020
@@ -554,6 +579,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
             }
           }
         }
+        SG_PROF(4);
         if (seg == SEG_AFTER_F3) {
           if (code) {  // :1145
             stop = code;
@@ -621,6 +647,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
             seg = SEG_DE_TOP;
           }
         }
+        SG_PROF(5);
         if (seg == SEG_CRASH) {  // de returns iflag = 3 (ode_RAYS.f90:566-575), SG_ode_m.f90:139-149
           rel_err = eps * releps;
           abs_err = eps * abseps;
@@ -636,6 +663,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
             seg = SEG_DE_BEGIN;
           }
         }
+        SG_PROF(6);
         if (seg == SEG_DE_BEGIN) {
           // ---- de parameter tests + restart (ode_RAYS.f90:423-505); y == vst, t, tout set ----
           if (t == tout) {
@@ -667,6 +695,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
             }
           }
         }
+        SG_PROF(7);
         if (seg == SEG_DE_TOP) {
           if (absdel <= fabs(x - t)) {
             // ---- intrp (ode_RAYS.f90:1235-1362) -> y(tout); interval done (:511-518) ----
@@ -739,6 +768,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
             }
           }
         }
+        SG_PROF(8);
         if (seg == SEG_START_DONE) {
           have_f = 0;
           if (code) {  // :863 stop inside f: y, t untouched
@@ -772,6 +802,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
             seg = SEG_COEF;
           }
         }
+        SG_PROF(9);
         if (seg == SEG_COEF) {
           // ---- coefficients + predictor (ode_RAYS.f90:892-1015) ----
           const int kp1 = k + 1, kp2 = k + 2;
@@ -840,6 +871,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
               S.g(i) = w[1];
             }
           }
+          SG_PROF(12);  // coefficient block
           F.scale(nsp1, k, [&](int i) { return S.beta(i); });
           {
             double row[NV];
@@ -852,7 +884,9 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
             }
             F.set(kp1, row);  // phi(:,kp1) = 0
           }
+          SG_PROF(13);  // scale + shift
           F.predict(k, [&](int i) { return S.g(i); }, pp);
+          SG_PROF(14);  // predictor
           if (!(fl & FL_NORND)) {
 #pragma unroll
             for (int l = 0; l < NV; l++) {
@@ -870,6 +904,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
           pc = PC_F2;
           seg = SEG_WAIT;
         }
+        SG_PROF(10);
         if (seg == SEG_STOP) {
           done = 1;
 #ifdef RAYS_SG_DEBUG
@@ -880,6 +915,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
         }
       }
 
+      SG_PROF(11);
       if (done && stop >= 0) {  // ray_tracing.f90:252-260
         const TraceArgs& A = cold_args(A_hot);
         A.npoints[ray] = nstep + 1;
@@ -907,6 +943,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
       }
     }
   }
+  SG_PROF_FLUSH
 }
 
 }  // namespace rays
