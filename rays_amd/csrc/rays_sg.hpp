@@ -336,12 +336,20 @@ struct SgPhi {
   }
 };
 
-// gstr(1:13) -- single-precision literals widened to double (ode_RAYS.f90:776-779)
-__device__ static const double kGstr[14] = {
-    0., (double)0.50e+00f, (double)0.0833e+00f, (double)0.0417e+00f, (double)0.0264e+00f,
-    (double)0.0188e+00f, (double)0.0143e+00f, (double)0.0114e+00f, (double)0.00936e+00f,
-    (double)0.00789e+00f, (double)0.00679e+00f, (double)0.00592e+00f, (double)0.00524e+00f,
-    (double)0.00468e+00f};
+// gstr(1:13) -- single-precision literals widened to double (ode_RAYS.f90:776-779).  Indexed by the
+// lane's order: a select chain over compile-time constants (a table in global memory cost a waited
+// ~0.7 us load per use, four uses per step).
+RAYS_DEV double gstr(int i) {
+  constexpr double t[14] = {
+      0., (double)0.50e+00f, (double)0.0833e+00f, (double)0.0417e+00f, (double)0.0264e+00f,
+      (double)0.0188e+00f, (double)0.0143e+00f, (double)0.0114e+00f, (double)0.00936e+00f,
+      (double)0.00789e+00f, (double)0.00679e+00f, (double)0.00592e+00f, (double)0.00524e+00f,
+      (double)0.00468e+00f};
+  double r = 0.;
+#pragma unroll
+  for (int q = 1; q <= 13; q++) r = i == q ? t[q] : r;
+  return r;
+}
 
 template <int EQ, int NS, int DERIV, int NV>
 __global__ void __launch_bounds__(256)
@@ -527,10 +535,10 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
               const double q = div(f[l] - ph1, wt[l]);
               erk = erk + q * q;
             }
-            if (0 < km2) erkm2 = absh * S.sig(km1) * kGstr[km2] * sqrt(erkm2);
-            if (0 <= km2) erkm1 = absh * S.sig(k) * kGstr[km1] * sqrt(erkm1);
+            if (0 < km2) erkm2 = absh * S.sig(km1) * gstr(km2) * sqrt(erkm2);
+            if (0 <= km2) erkm1 = absh * S.sig(k) * gstr(km1) * sqrt(erkm1);
             const double err = absh * sqrt(erk) * (S.g(k) - S.g(kp1));
-            erk = absh * sqrt(erk) * S.sig(kp1) * kGstr[k];
+            erk = absh * sqrt(erk) * S.sig(kp1) * gstr(k);
             knew = k;
             if (0 < km2) {
               if (fmax(erkm1, erkm2) <= erk) knew = km1;
@@ -611,7 +619,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
                 const double q = div(d2[l], wt[l]);
                 erkp1 = erkp1 + q * q;
               }
-              erkp1 = absh * kGstr[kp1] * sqrt(erkp1);
+              erkp1 = absh * gstr(kp1) * sqrt(erkp1);
               if (k == 1) {
                 if (erkp1 < 0.5 * erk) {
                   k = kp1;
