@@ -444,9 +444,6 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
     // ---- per-lane continuation -------------------------------------------------------------------
     int stop = 0;
     int done = 0;
-#ifdef RAYS_SG_DEBUG
-    double dbg[7] = {-1, -1, -1, -1, -1, -1, -1};
-#endif
     if (act) {
       int seg;
       int have_f = 0;  // f(x, yy) for start = true is already in f[]
@@ -915,10 +912,6 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
         SG_PROF(10);
         if (seg == SEG_STOP) {
           done = 1;
-#ifdef RAYS_SG_DEBUG
-          dbg[0] = (double)stop; dbg[1] = (double)pc; dbg[2] = (double)nostep; dbg[3] = (double)k;
-          dbg[4] = (double)code; dbg[5] = t; dbg[6] = tout;
-#endif
           seg = SEG_WAIT;
         }
       }
@@ -933,9 +926,6 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
           for (int i = 0; i < NV; i++) A.end_ray_vec[(long long)ray * NV + i] = vst[i];
         if (A.end_residuals) A.end_residuals[ray] = nstep >= 1 ? prev_resid : 0.;
         if (A.max_residuals) A.max_residuals[ray] = maxr;
-#ifdef RAYS_SG_DEBUG
-        for (int i = 0; i < 7; i++) A.end_ray_vec[(long long)ray * NV + i] = dbg[i];
-#endif
       }
     }
 

@@ -116,3 +116,16 @@ def test_product_fails_loudly_without_gpu():
     g, nml, p = load_golden("cfg1_slab16_rk4")
     with pytest.raises(hip.RaysHipError):
         hip.trace_host(p, g["rvec0"], g["rindex_vec0"])
+
+
+def test_scan_values_match_scanner_m():
+    """ray_scan parameter sequences (scanner_m.f90:115-160)."""
+    from rays_amd.scan import scan_values
+    np.testing.assert_array_equal(scan_values("fixed_increment", 4, p_start=2.5e-11, p_incr=1.25e-11),
+                                  2.5e-11 + np.arange(4) * 1.25e-11)
+    d = float(np.float32(1.0e-14))
+    np.testing.assert_array_equal(scan_values("pwr_of_2", 3, p_max=1.0), np.array([0.25, 0.5, 1.0]) - d)
+    np.testing.assert_array_equal(scan_values("integer_divide", 3, p_max=1.0, max_divide=4),
+                                  1.0 / np.array([4.0, 3.0, 2.0]))
+    with pytest.raises(ValueError):
+        scan_values("nope", 2)
