@@ -32,6 +32,8 @@ CASES = [
     ("gold_solovev64_rk4_num", "gold_solovev64_rk4_num.in", list(range(0, 64, 5)), 0, 0),
     # non-unit profile exponents: the general (libm pow) kernels
     ("gold_solovev64_pow_rk4", "gold_solovev64_pow_rk4.in", list(range(0, 64, 5)), 20, 120),
+    # a fan reaching past the cutoff: evanescent launches dropped by the ray launcher (ray numbering)
+    ("gold_solovev_evanescent_rk4", "gold_solovev_evanescent_rk4.in", None, 0, 0),
     # fundamental-ECH damping (damp_fund_ECH, nv = 8): constant density + parabolic Te, B0 = 3.3 T
     ("gold_solovev64_damp_rk4", "gold_solovev64_damp_rk4.in", list(range(0, 64, 5)), 0, 0),
     ("gold_solovev64_damp_sg", "gold_solovev64_damp_sg.in", list(range(0, 64, 5)), 0, 0),

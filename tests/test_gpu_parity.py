@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 # reference's glibc pow: within the 1e-10 bar, not necessarily bitwise); every other case has unit
 # exponents and runs the unit-exponent kernels
 RK4_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_num", "gold_solovev64_pow_rk4",
+             "gold_solovev_evanescent_rk4",
              "gold_solovev64_damp_rk4", "gold_axisym64_eqdsk_damp_rk4"]
 SG_CASES = ["gold_solovev64_sg_cold", "gold_solovev64_sg_num", "gold_solovev64_damp_sg"]
 
