@@ -22,6 +22,9 @@
 namespace rays {
 
 #define RAYS_DEV __device__ __forceinline__
+// rare per-ray events (a ray starts, stops, crashes): block-frequency hint for the register allocator,
+// which otherwise assumes 50 % and keeps their operands in reach on every trip
+#define RAYS_RARE(x) __builtin_expect(!!(x), 0)
 
 // ---------------------------------------------------------------------------------------------
 // Device parameter block: rays_params_t trimmed to what the kernels read, plus values the

@@ -402,7 +402,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
   SG_PROF_DECL
   while (__any(alive)) {
     SG_PROF(0);  // loop overhead, refill
-    if (need_init) {  // ray_tracing.f90:77-93, SG_ode_m.f90:73-85
+    if (RAYS_RARE(need_init)) {  // ray_tracing.f90:77-93, SG_ode_m.f90:73-85
       const TraceArgs& A = cold_args(A_hot);  // rays_trace.hpp
       initialize_ode_vector<EQ, NS, NV>(P, A.rvec0 + 3ll * ray, A.rindex_vec0 + 3ll * ray, vst);
       pc = PC_CHECK;
@@ -449,10 +449,10 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
       int have_f = 0;  // f(x, yy) for start = true is already in f[]
       if (pc == PC_CHECK) {
         seg = SEG_DE_BEGIN;
-        if (fl & FL_FIRST) {  // ray_tracing.f90:92-112
+        if (RAYS_RARE(fl & FL_FIRST)) {  // ray_tracing.f90:92-112
           record_point<NV>(cold_args(A_hot), (long long)ray * npt, vst, 0.);
           fl &= ~FL_FIRST;
-          if (cs_stop) {
+          if (RAYS_RARE(cs_stop)) {
             const TraceArgs& A = cold_args(A_hot);
             A.npoints[ray] = 1;
             A.stop_code[ray] = cs_flag;
@@ -467,7 +467,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
           }
         } else {
           // the interval completed: vst is y(tout)  (ray_tracing.f90:212-243)
-          if (cs_stop) {
+          if (RAYS_RARE(cs_stop)) {
             stop = cs_flag;
             seg = SEG_STOP;
           } else {
@@ -506,7 +506,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
       SG_PROF(3);  // CHECK bookkeeping
       while (seg != SEG_WAIT) {
         if (seg == SEG_AFTER_F2) {
-          if (code) {  // :1020
+          if (RAYS_RARE(code)) {  // :1020
             stop = code;
             seg = SEG_STOP;
           } else {
@@ -586,7 +586,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
         }
         SG_PROF(4);
         if (seg == SEG_AFTER_F3) {
-          if (code) {  // :1145
+          if (RAYS_RARE(code)) {  // :1145
             stop = code;
             seg = SEG_STOP;
           } else {
@@ -653,7 +653,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
           }
         }
         SG_PROF(5);
-        if (seg == SEG_CRASH) {  // de returns iflag = 3 (ode_RAYS.f90:566-575), SG_ode_m.f90:139-149
+        if (RAYS_RARE(seg == SEG_CRASH)) {  // de returns iflag = 3 (ode_RAYS.f90:566-575), SG_ode_m.f90:139-149
           rel_err = eps * releps;
           abs_err = eps * abseps;
 #pragma unroll
@@ -776,7 +776,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
         SG_PROF(8);
         if (seg == SEG_START_DONE) {
           have_f = 0;
-          if (code) {  // :863 stop inside f: y, t untouched
+          if (RAYS_RARE(code)) {  // :863 stop inside f: y, t untouched
             stop = code;
             seg = SEG_STOP;
           } else {  // :865-885
@@ -910,14 +910,14 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
           seg = SEG_WAIT;
         }
         SG_PROF(10);
-        if (seg == SEG_STOP) {
+        if (RAYS_RARE(seg == SEG_STOP)) {
           done = 1;
           seg = SEG_WAIT;
         }
       }
 
       SG_PROF(11);
-      if (done && stop >= 0) {  // ray_tracing.f90:252-260
+      if (RAYS_RARE(done && stop >= 0)) {  // ray_tracing.f90:252-260
         const TraceArgs& A = cold_args(A_hot);
         A.npoints[ray] = nstep + 1;
         A.stop_code[ray] = stop;
@@ -930,7 +930,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
     }
 
     // ---- refill finished lanes ---------------------------------------------------------------
-    if (done) {
+    if (RAYS_RARE(done)) {
       const TraceArgs& A = cold_args(A_hot);
       const unsigned nxt = atomicAdd(A.next_ray, 1u) + total_lanes;
       if (nxt < (unsigned)A.nray) {
