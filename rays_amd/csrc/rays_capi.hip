@@ -680,6 +680,15 @@ int rays_hip_ray_init(const rays_params_t* p, const rays_fan_t* fan, int nray_ma
                       double* rindex_vec0, double* ray_pwr_wt, int32_t* nray) {
   if (!rvec0 || !rindex_vec0 || !nray) return fail("rays_hip_ray_init: null pointer");
   if (nray_max <= 0) return fail("rays_hip_ray_init: nray_max <= 0");
+  {  // configuration errors first (they need no device), as the reference's launchers `stop 1`
+    int rc0 = rays_hip_check_params(p);
+    if (rc0) return rc0;
+    rays::FanArgs F;
+    std::vector<double> launch;
+    int per_r0 = 0;
+    const char* why = "";
+    if (fan_setup(p, fan, nray_max, &F, &launch, &per_r0, &why)) return fail(why);
+  }
   double *d_r = nullptr, *d_n = nullptr;
   HIP_TRY(hipMalloc(&d_r, sizeof(double) * 3 * (size_t)nray_max));
   if (hipMalloc(&d_n, sizeof(double) * 3 * (size_t)nray_max) != hipSuccess) {

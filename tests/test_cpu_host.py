@@ -129,3 +129,31 @@ def test_scan_values_match_scanner_m():
                                   1.0 / np.array([4.0, 3.0, 2.0]))
     with pytest.raises(ValueError):
         scan_values("nope", 2)
+
+
+def test_ray_launcher_and_deposition_config_errors_need_no_gpu():
+    """rays_hip_ray_init / rays_hip_deposition_device reject what the reference's launchers and
+    post-processor `stop 1` on, before touching a device."""
+    import ctypes as C
+    from rays_amd.params import copy_params
+    from rays_amd.ray_init import fan_from_namelist
+    g, nml, p = load_golden("cfg2_solovev1024_rk4")
+    fan, nray_max = fan_from_namelist(nml)
+    bad = type(fan).from_buffer_copy(fan)
+    bad.wave_mode = 7
+    with pytest.raises(hip.RaysHipError, match="wave_mode"):
+        hip.ray_init_host(p, bad, nray_max)
+    with pytest.raises(hip.RaysHipError, match="improper number of rays"):
+        hip.ray_init_host(p, fan, 10)                      # nray_max < n_r*n_theta*n_ntheta*n_nphi
+    slab = type(fan).from_buffer_copy(fan)
+    slab.model = 2                                         # simple_slab launcher on a Solovev equilibrium
+    with pytest.raises(hip.RaysHipError, match="slab"):
+        hip.ray_init_host(p, slab, nray_max)
+    # deposition: needs axisym_toroid + damping
+    with pytest.raises(hip.RaysHipError, match="axisym_toroid"):
+        hip.deposition_device(p, "Ptotal_psi", 100, 1, 1, 1, 1, 1, None, 1)
+    ga, nmla, pa = load_golden("gold_axisym64_eqdsk_damp_rk4")
+    q = copy_params(pa)
+    q.nv, q.damping_model = 7, 0
+    with pytest.raises(hip.RaysHipError, match="damping"):
+        hip.deposition_device(q, "Ptotal_psi", 100, 1, 1, 1, 1, 1, None, 1)

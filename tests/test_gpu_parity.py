@@ -170,3 +170,15 @@ def test_device_deposition_profiles_match_reference():
                               power[h:].data_ptr(), w2.data_ptr(), part.data_ptr(), tot.data_ptr())
         torch.cuda.synchronize()
         np.testing.assert_array_equal(tot.cpu().numpy(), g["dep_profile"][which])
+
+
+def test_device_ray_init_all_evanescent_and_missing_rho_table():
+    """Launcher error behaviour on the device path: a fan entirely past the cutoff ends with the
+    reference's 'No successful ray initializations'."""
+    from rays_amd.ray_init import fan_from_namelist
+    g, nml, p = load_golden("gold_solovev_evanescent_rk4")
+    fan, nray_max = fan_from_namelist(nml)
+    far = type(fan).from_buffer_copy(fan)
+    far.rindex_theta0, far.delta_rindex_theta = 5.0, 0.1     # |n_theta| >> 1 everywhere: evanescent
+    with pytest.raises(hip.RaysHipError, match="No successful ray initializations"):
+        hip.ray_init_host(p, far, nray_max)
