@@ -301,7 +301,7 @@ def main():
                        "recorded_steps_per_pass": total_steps, "nstep_max": p.nstep_max,
                        "ode": "RK4_ODE" if p.ode_solver == 0 else "SG_ODE",
                        "deriv": "cold" if p.ray_deriv == 0 else "numerical",
-                       "kernel": hip.kernel_name(p),
+                       "kernel": hip.kernel_name(p, hi - lo),
                        "exchange": ("none" if world == 1 else
                                     ("skipped" if args.no_gather else "packed send/recv to rank 0 (RCCL)"))
                        if args.exchange == "gather" else

@@ -232,6 +232,8 @@ int rays_hip_trace_device(const rays_params_t* p, int nray,
 /* Name of the kernel specialisation rays_hip_trace_device would launch for p (for profiling
  * scripts: matches the rocprofv3 kernel-trace name prefix). */
 const char* rays_hip_kernel_name(const rays_params_t* p);
+/* Same for a fan of nray rays: large fans may get a differently tuned build of the kernel. */
+const char* rays_hip_kernel_name_for(const rays_params_t* p, int nray);
 
 /* ---- multi-GPU trajectory exchange helpers ---------------------------------
  * The padded reference layout is mostly zeros (a ray uses npoints of nstep_max+1 slots).  Before

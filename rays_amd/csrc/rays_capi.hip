@@ -102,7 +102,9 @@ const FlagText kFlags[] = {
 
 #include "rays_dev_params.inc"
 
-const rays::KernelEntry* find_kernel(const rays_params_t& p) {
+// nray: fan size (0 = unknown).  From two waves per SIMD worth of rays on, the two-waves-per-SIMD build
+// of the kernel is preferred where one exists (rays_rk4.hpp).
+const rays::KernelEntry* find_kernel(const rays_params_t& p, long long nray = 0) {
   using namespace rays;
   typedef const KernelEntry* (*Getter)(int*);
 #define RAYS_G(s, e, d) {rays_entries_##s##_##e##_##d##_0, rays_entries_##s##_##e##_##d##_1}
@@ -112,9 +114,21 @@ const rays::KernelEntry* find_kernel(const rays_params_t& p) {
 #undef RAYS_G
   int n = 0;
   const KernelEntry* e = getters[p.ode_solver][p.equilib_model][p.ray_deriv][unit_exponents(p) ? 1 : 0](&n);
+  int ncu = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (nray > 0 && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      ncu = prop.multiProcessorCount;
+  }
+  const bool big = nray >= 2ll * ncu * 256;  // >= two waves per SIMD
+  const KernelEntry* found = nullptr;
   for (int i = 0; i < n; i++)
-    if (e[i].ns == p.nspec + 1 && e[i].nv == p.nv) return &e[i];
-  return nullptr;
+    if (e[i].ns == p.nspec + 1 && e[i].nv == p.nv) {
+      if (e[i].occ == 1 && !found) found = &e[i];
+      if (e[i].occ == 2 && big) return &e[i];
+    }
+  return found;
 }
 
 // Z-function spline table (host copy + lazily uploaded per-device copies)
@@ -348,6 +362,11 @@ const char* rays_hip_kernel_name(const rays_params_t* p) {
   return find_kernel(*p)->name;
 }
 
+const char* rays_hip_kernel_name_for(const rays_params_t* p, int nray) {
+  if (!p || rays_hip_check_params(p)) return "";
+  return find_kernel(*p, nray)->name;
+}
+
 int rays_hip_trace_device(const rays_params_t* p, int nray, const double* d_rvec0,
                           const double* d_rindex_vec0, double* d_ray_vec, double* d_residual,
                           int32_t* d_npoints, int32_t* d_stop_code, double* d_end_ray_vec,
@@ -403,7 +422,7 @@ int rays_hip_trace_device(const rays_params_t* p, int nray, const double* d_rvec
     if (need_ne || need_t) return fail("axisym_toroid: spline profile model selected but its table was not set");
   }
   int grid = 0;
-  hipError_t e = find_kernel(*p)->launch(D, A, stream, &grid);
+  hipError_t e = find_kernel(*p, nray)->launch(D, A, stream, &grid);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
   return 0;
 }

@@ -32,9 +32,10 @@ constexpr int EQ = RAYS_INST_EQT;
 static_assert(EQ == (RAYS_INST_EQ | (RAYS_INST_UE ? kEqUnitExp : 0)), "EQ encoding");
 constexpr int DERIV = RAYS_INST_DERIV;
 
-template <int NS, int NV>
+template <int NS, int NV, int OCC = 1>
 hipError_t launch_one(const DevParams& P, const TraceArgs& A, hipStream_t stream, int* grid_blocks) {
 #if RAYS_INST_SOLVER == 0
+  if (OCC == 2) return launch_persistent(rk4_trace_kernel_w2<EQ, NS, DERIV, NV>, 0, P, A, stream, grid_blocks);
   return launch_persistent(rk4_trace_kernel<EQ, NS, DERIV, NV>, 0, P, A, stream, grid_blocks);
 #else
   constexpr size_t lds = (size_t)(kBlock / kWave) * SgLds<NV>::kDoublesPerWave * sizeof(double);
@@ -48,17 +49,28 @@ hipError_t launch_one(const DevParams& P, const TraceArgs& A, hipStream_t stream
 #define RAYS_KNAME "sg_trace_kernel"
 #endif
 #define RAYS_ENTRY(NS, NV) \
-  { RAYS_INST_SOLVER, EQ, NS, DERIV, NV, RAYS_KNAME "<" RAYS_STR(RAYS_INST_EQT) ", " #NS ", " RAYS_STR(RAYS_INST_DERIV) ", " #NV ">", &launch_one<NS, NV> }
+  { RAYS_INST_SOLVER, EQ, NS, DERIV, NV, 1, RAYS_KNAME "<" RAYS_STR(RAYS_INST_EQT) ", " #NS ", " RAYS_STR(RAYS_INST_DERIV) ", " #NV ">", &launch_one<NS, NV> }
+// two-waves-per-SIMD build of an RK4 kernel (large fans; rays_rk4.hpp)
+#define RAYS_ENTRY_OCC2(NS, NV) \
+  { RAYS_INST_SOLVER, EQ, NS, DERIV, NV, 2, "rk4_trace_kernel_w2<" RAYS_STR(RAYS_INST_EQT) ", " #NS ", " RAYS_STR(RAYS_INST_DERIV) ", " #NV ">", &launch_one<NS, NV, 2> }
 
 const KernelEntry kEntries[] = {
 #ifdef RAYS_INST_FAST  // developer builds (make FAST=1): electrons + one ion species only
     RAYS_ENTRY(2, 7), RAYS_ENTRY(2, 8),
+#if RAYS_INST_SOLVER == 0 && RAYS_INST_EQ != 2
+    RAYS_ENTRY_OCC2(2, 7),
+#endif
 #else
     RAYS_ENTRY(1, 7), RAYS_ENTRY(2, 7), RAYS_ENTRY(3, 7), RAYS_ENTRY(4, 7), RAYS_ENTRY(5, 7), RAYS_ENTRY(6, 7),
     RAYS_ENTRY(1, 12), RAYS_ENTRY(2, 12), RAYS_ENTRY(3, 12), RAYS_ENTRY(4, 12), RAYS_ENTRY(5, 12), RAYS_ENTRY(6, 12),
     // nv = 8 | 13: + total-absorption row (damping_model = 'damp_fund_ECH', ode_m.f90:162-166)
     RAYS_ENTRY(1, 8), RAYS_ENTRY(2, 8), RAYS_ENTRY(3, 8), RAYS_ENTRY(4, 8), RAYS_ENTRY(5, 8), RAYS_ENTRY(6, 8),
     RAYS_ENTRY(1, 13), RAYS_ENTRY(2, 13), RAYS_ENTRY(3, 13), RAYS_ENTRY(4, 13), RAYS_ENTRY(5, 13), RAYS_ENTRY(6, 13),
+#if RAYS_INST_SOLVER == 0 && RAYS_INST_EQ != 2
+    // the common analytic-equilibrium shapes also built for two waves per SIMD (the eqdsk + damping
+    // kernels lose at 128 VGPRs: 4.4 -> 7.0 ms on the 256k-ray eqdsk fan)
+    RAYS_ENTRY_OCC2(1, 7), RAYS_ENTRY_OCC2(2, 7), RAYS_ENTRY_OCC2(3, 7),
+#endif
 #endif
 };
 }  // namespace

@@ -23,9 +23,9 @@
 
 namespace rays {
 
+// The kernel body; the two __global__ wrappers below differ only in their launch bounds.
 template <int EQ, int NS, int DERIV, int NV>
-__global__ void __launch_bounds__(256)
-rk4_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
+RAYS_DEV void rk4_trace_body(const DevParams& P_kernarg, const TraceArgs& A_hot) {
   DevParams P;  // working copy: scalarised by the compiler, hot constants in vector registers
   hot_params<EQ, NS>(P_kernarg, P);
 
@@ -183,5 +183,30 @@ rk4_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
     }
   }
 }
+
+#ifndef RAYS_HOST_EMUL
+// One wave per SIMD (all 256 VGPRs): fastest while the fan has at most one wave per SIMD (<= 64k rays).
+template <int EQ, int NS, int DERIV, int NV>
+__global__ void __launch_bounds__(256)
+rk4_trace_kernel(const DevParams P, const TraceArgs A) {
+  rk4_trace_body<EQ, NS, DERIV, NV>(P, A);
+}
+
+// Two waves per SIMD (128 VGPRs, spills): from two waves' worth of rays on this build wins, because
+// two waves share a SIMD's issue slots better than one (tools/ubench: 4.6 vs 5.5 clocks per FP64 op).
+// Measured on the Solovev fan: -2 % at 64k rays, +4 % at 128k, +11 % at 1M.  rays_capi.hip:
+// find_kernel picks by fan size.  (The launch bound must be a literal: hipcc ignores a
+// template-dependent second argument.)
+template <int EQ, int NS, int DERIV, int NV>
+__global__ void __launch_bounds__(256, 2)
+rk4_trace_kernel_w2(const DevParams P, const TraceArgs A) {
+  rk4_trace_body<EQ, NS, DERIV, NV>(P, A);
+}
+#else
+template <int EQ, int NS, int DERIV, int NV>
+void rk4_trace_kernel(const DevParams P, const TraceArgs A) {
+  rk4_trace_body<EQ, NS, DERIV, NV>(P, A);
+}
+#endif
 
 }  // namespace rays

@@ -20,7 +20,7 @@ EXPORTED_SYMBOLS = (
     "rays_hip_init", "rays_hip_finalize", "rays_hip_device_count", "rays_hip_sizeof_params",
     "rays_hip_last_error", "rays_hip_set_zfun_table", "rays_hip_set_axisym_tables",
     "rays_hip_stop_flag_text", "rays_hip_check_params", "rays_hip_trace", "rays_hip_trace_device",
-    "rays_hip_kernel_name", "rays_hip_probe", "rays_hip_pack_device", "rays_hip_unpack_device",
+    "rays_hip_kernel_name", "rays_hip_kernel_name_for", "rays_hip_probe", "rays_hip_pack_device", "rays_hip_unpack_device",
     "rays_hip_sizeof_fan", "rays_hip_ray_init", "rays_hip_ray_init_device",
     "rays_hip_set_rho_table", "rays_hip_deposition_device",
 )
@@ -63,6 +63,8 @@ def load():
     lib.rays_hip_check_params.argtypes = [pp]
     lib.rays_hip_kernel_name.restype = C.c_char_p
     lib.rays_hip_kernel_name.argtypes = [pp]
+    lib.rays_hip_kernel_name_for.restype = C.c_char_p
+    lib.rays_hip_kernel_name_for.argtypes = [pp, C.c_int]
     lib.rays_hip_trace.restype = C.c_int
     lib.rays_hip_trace.argtypes = [pp, C.c_int, dp, dp, dp, dp, ip, ip, dp, dp, dp, dp]
     lib.rays_hip_trace_device.restype = C.c_int
@@ -136,7 +138,10 @@ def check_params(p: RaysParams):
     _check(load().rays_hip_check_params(C.byref(p)), "rays_hip_check_params")
 
 
-def kernel_name(p: RaysParams) -> str:
+def kernel_name(p: RaysParams, nray: int = 0) -> str:
+    """Kernel specialisation a trace of `nray` rays would launch (0: the default build)."""
+    if nray:
+        return load().rays_hip_kernel_name_for(C.byref(p), int(nray)).decode()
     return load().rays_hip_kernel_name(C.byref(p)).decode()
 
 

@@ -172,3 +172,27 @@ def test_fused_ray_scan_equals_separate_runs():
         np.testing.assert_array_equal(r.stop_code, ref["stop_code"])
         np.testing.assert_array_equal(r.ray_vec, ref["ray_vec"])
         np.testing.assert_array_equal(r.residual, ref["residual"])
+
+
+def test_large_fan_kernel_build_equals_small_fan_build():
+    """Fans of >= 2 waves per SIMD run the two-waves-per-SIMD build of the RK4 kernel (rays_rk4.hpp: OCC);
+    its results are bit-identical to the one-wave build's (same fan traced in two halves)."""
+    import torch
+    from rays_amd.trace import DeviceTrace
+    g, nml, p = load_golden("cfg2_solovev1024_rk4")
+    q = copy_params(p)
+    q.nstep_max = 24
+    reps = 131072 // len(g["rvec0_full"]) + 1
+    r0 = np.tile(g["rvec0_full"], (reps, 1))[:131072 + 640]
+    n0 = np.tile(g["rindex_vec0_full"], (reps, 1))[:131072 + 640]
+    big = DeviceTrace(q, r0, n0)
+    big.launch()
+    h = len(r0) // 2
+    a, b = DeviceTrace(q, r0[:h], n0[:h]), DeviceTrace(q, r0[h:], n0[h:])
+    a.launch()
+    b.launch()
+    torch.cuda.synchronize()
+    for name in ("ray_vec", "residual", "npoints", "stop_code", "end_ray_vec", "max_residuals"):
+        whole = getattr(big, name)
+        assert torch.equal(whole[:h], getattr(a, name)) and torch.equal(whole[h:], getattr(b, name)), name
+    assert int(big.npoints.sum()) > len(r0)

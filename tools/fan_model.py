@@ -3,6 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
+from rays_amd import hip
 from rays_amd.trace import DeviceTrace
 
 def run(cfg, fan_scale=1, nstep_max=None, reps=5):
@@ -21,18 +22,20 @@ def run(cfg, fan_scale=1, nstep_max=None, reps=5):
     wmax = pad.reshape(nw, 64).max(1)
     print(f"{os.path.basename(cfg)} x{fan_scale}: nray={len(st)} steps={st.sum()} mean={st.mean():.1f} max={st.max()} "
           f"wave-max mean={wmax.mean():.1f} | {ms:.3f} ms  -> {st.sum()/ms/1e6:.3f} Gsteps/s; "
-          f"us/step(longest)={ms*1e3/st.max():.2f}  lane-util={st.sum()/(wmax.sum()*64):.3f}", flush=True)
+          f"us/step(longest)={ms*1e3/st.max():.2f}  lane-util={st.sum()/(wmax.sum()*64):.3f}  "
+          f"{hip.kernel_name(p, len(st))}", flush=True)
     return ms, st
 
-cfg = "configs/cfg3b_solovev64k_rk4.in"
-print("lib:", os.environ.get("RAYS_HIP_LIB", "default"))
-if len(sys.argv) > 1 and sys.argv[1] == "short":
-    run(cfg, reps=10)
-    run(cfg, 1, 100, reps=10)
-    run(cfg, 4, 400)
-else:
-    run(cfg)
-    for nm in (100, 200, 400):
-        run(cfg, 1, nm)
-    run(cfg, 4, 400)
-    run("configs/cfg1_slab16_rk4.in")
+if __name__ == "__main__":
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs/cfg3b_solovev64k_rk4.in")
+    print("lib:", os.environ.get("RAYS_HIP_LIB", "default"))
+    if len(sys.argv) > 1 and sys.argv[1] == "short":
+        run(cfg, reps=10)
+        run(cfg, 1, 100, reps=10)
+        run(cfg, 4, 400)
+    else:
+        run(cfg)
+        for nm in (100, 200, 400):
+            run(cfg, 1, nm)
+        run(cfg, 4, 400)
+        run("configs/cfg1_slab16_rk4.in")
