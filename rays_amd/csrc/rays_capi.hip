@@ -427,6 +427,39 @@ int rays_hip_trace_device(const rays_params_t* p, int nray, const double* d_rvec
   return 0;
 }
 
+// Pinned staging for the packed device-to-host copy of rays_hip_trace: two buffers per device,
+// allocated once (pinning is slow) and kept.  `points` = trajectory points one buffer holds.
+struct StagingBuffers {
+  double* vec[2] = {nullptr, nullptr};
+  double* res[2] = {nullptr, nullptr};
+  long long points = 0;
+  size_t nv = 0;
+};
+static std::vector<StagingBuffers> g_staging;
+static StagingBuffers* staging_for_device(int dev, size_t nv) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if ((int)g_staging.size() <= dev) g_staging.resize(dev + 1);
+  StagingBuffers& sb = g_staging[dev];
+  if (sb.points == 0 || sb.nv < nv) {
+    for (int b = 0; b < 2; b++) {
+      if (sb.vec[b]) (void)hipHostFree(sb.vec[b]);
+      if (sb.res[b]) (void)hipHostFree(sb.res[b]);
+      sb.vec[b] = sb.res[b] = nullptr;
+    }
+    const long long pts = 1ll << 20;  // 1 M points per buffer: 8 (nv + 1) MB, e.g. 64 MB for nv = 7
+    for (int b = 0; b < 2; b++) {
+      if (hipHostMalloc((void**)&sb.vec[b], sizeof(double) * nv * (size_t)pts, hipHostMallocDefault) != hipSuccess ||
+          hipHostMalloc((void**)&sb.res[b], sizeof(double) * (size_t)pts, hipHostMallocDefault) != hipSuccess) {
+        sb.points = 0;
+        return nullptr;
+      }
+    }
+    sb.points = pts;
+    sb.nv = nv;
+  }
+  return &sb;
+}
+
 // One device's share of rays_hip_trace: rays [r0, r1) -> contiguous slabs of the host arrays.
 static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1, const double* rvec0,
                                  const double* rindex_vec0, double* ray_vec, double* residual,
@@ -471,14 +504,93 @@ static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1
     DEV_CHK(hipMalloc(&d_mr, sizeof(double) * n));
     DEV_CHK(hipMemcpyAsync(d_r, rvec0 + 3 * (size_t)r0, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
     DEV_CHK(hipMemcpyAsync(d_n, rindex_vec0 + 3 * (size_t)r0, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
-    rc = rays_hip_trace_device(p, n, d_r, d_n, d_rv, d_res, d_np, d_sc, d_ev, d_er, d_mr, st, 0);
+    // no zero-fill of the device arrays: only recorded points are read back
+    rc = rays_hip_trace_device(p, n, d_r, d_n, d_rv, d_res, d_np, d_sc, d_ev, d_er, d_mr, st, RAYS_TRACE_NO_ZERO_FILL);
     if (rc) {
       bail(rc);
       break;
     }
-    DEV_CHK(hipMemcpyAsync(ray_vec + npt * nv * (size_t)r0, d_rv, sizeof(double) * npt * nv * n, hipMemcpyDeviceToHost, st));
-    DEV_CHK(hipMemcpyAsync(residual + npt * (size_t)r0, d_res, sizeof(double) * npt * n, hipMemcpyDeviceToHost, st));
+    // ---- trajectories: only the recorded points cross PCIe ------------------------------------
+    // The padded arrays are ~80 % zeros (a ray uses npoints of nstep_max+1 slots; 4.7 GB for the 64k
+    // fan, 0.82 GB of it data).  Pack on the device, copy the packed block through two pinned
+    // staging buffers, and scatter it into the caller's arrays with host threads while the next
+    // chunk is in flight.  Entries past npoints are not written: like the reference's trace_rays,
+    // which relies on initialize_ray_results_m having zero-filled the arrays (ray_results_m.f90:
+    // 154-164), this entry leaves them as the caller passed them.
     DEV_CHK(hipMemcpyAsync(npoints + r0, d_np, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    DEV_CHK(hipStreamSynchronize(st));
+    {
+      std::vector<long long> offs((size_t)n + 1);
+      offs[0] = 0;
+      for (int i = 0; i < n; i++) offs[(size_t)i + 1] = offs[i] + (npoints[r0 + i] > 0 ? npoints[r0 + i] : 0);
+      const long long total = offs[n];
+      long long* d_off = nullptr;
+      double *d_pv = nullptr, *d_pr = nullptr;
+      DEV_CHK(hipMalloc(&d_off, sizeof(long long) * ((size_t)n + 1)));
+      bool ok = true;
+      do {
+        if (total == 0) break;
+        if (hipMalloc(&d_pv, sizeof(double) * nv * (size_t)total) != hipSuccess ||
+            hipMalloc(&d_pr, sizeof(double) * (size_t)total) != hipSuccess) { ok = false; break; }
+        if (hipMemcpyAsync(d_off, offs.data(), sizeof(long long) * ((size_t)n + 1), hipMemcpyHostToDevice, st) != hipSuccess) { ok = false; break; }
+        if (rays::launch_pack(true, n, (int)nv, p->nstep_max, d_np, d_off, d_rv, d_res, d_pv, d_pr, st) != hipSuccess) { ok = false; break; }
+        StagingBuffers* sb = staging_for_device(dev, nv);
+        if (!sb) { ok = false; break; }
+        // chunks of rays whose packed size fits one staging buffer
+        int c0 = 0, buf = 0;
+        hipEvent_t ev[2];
+        if (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess) { ok = false; break; }
+        struct Chunk { int a, b, buf; };
+        Chunk pending{0, 0, -1};
+        auto scatter = [&](const Chunk& c) {   // host side of one chunk: packed staging -> padded arrays
+          const long long base = offs[c.a];
+          const double* sv = sb->vec[c.buf];
+          const double* sr = sb->res[c.buf];
+          const int nt = 8;
+          std::vector<std::thread> th;
+          for (int t = 0; t < nt; t++)
+            th.emplace_back([&, t]() {
+              for (int i = c.a + t; i < c.b; i += nt) {
+                const long long np_i = offs[(size_t)i + 1] - offs[i];
+                if (np_i <= 0) continue;
+                std::memcpy(ray_vec + npt * nv * (size_t)(r0 + i), sv + (offs[i] - base) * (long long)nv,
+                            sizeof(double) * nv * (size_t)np_i);
+                std::memcpy(residual + npt * (size_t)(r0 + i), sr + (offs[i] - base), sizeof(double) * (size_t)np_i);
+              }
+            });
+          for (auto& x : th) x.join();
+        };
+        while (c0 < n && ok) {
+          int c1 = c0;
+          while (c1 < n && offs[(size_t)c1 + 1] - offs[c0] <= sb->points) c1++;
+          if (c1 == c0) c1 = c0 + 1;  // (cannot happen: a ray has at most nstep_max+1 <= sb->points points)
+          const long long pts = offs[c1] - offs[c0];
+          if (pts > 0) {
+            if (hipMemcpyAsync(sb->vec[buf], d_pv + offs[c0] * (long long)nv, sizeof(double) * nv * (size_t)pts,
+                               hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(sb->res[buf], d_pr + offs[c0], sizeof(double) * (size_t)pts, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipEventRecord(ev[buf], st) != hipSuccess) { ok = false; break; }
+          }
+          if (pending.buf >= 0) scatter(pending);   // overlaps the copy just queued
+          if (pts > 0) {
+            if (hipEventSynchronize(ev[buf]) != hipSuccess) { ok = false; break; }
+            pending = Chunk{c0, c1, buf};
+            buf ^= 1;
+          } else {
+            pending.buf = -1;
+          }
+          c0 = c1;
+        }
+        if (ok && pending.buf >= 0) scatter(pending);
+        (void)hipEventDestroy(ev[0]);
+        (void)hipEventDestroy(ev[1]);
+      } while (0);
+      (void)hipFree(d_off); (void)hipFree(d_pv); (void)hipFree(d_pr);
+      if (!ok) {
+        rc = bail(fail("rays_hip_trace: packed device-to-host copy failed (out of memory?)"));
+        break;
+      }
+    }
     DEV_CHK(hipMemcpyAsync(stop_code + r0, d_sc, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
     if (end_ray_vec) DEV_CHK(hipMemcpyAsync(end_ray_vec + nv * (size_t)r0, d_ev, sizeof(double) * nv * n, hipMemcpyDeviceToHost, st));
     if (end_residuals) DEV_CHK(hipMemcpyAsync(end_residuals + r0, d_er, sizeof(double) * n, hipMemcpyDeviceToHost, st));

@@ -83,12 +83,12 @@ struct DevParams {
 //
 // The block is ~170 doubles and a wave has ~100 SGPRs.  LLVM keeps what fits in SGPRs and, for the
 // rest, re-issues the scalar kernarg load inside the wave loop right where the value is used, i.e.
-// s_load + s_waitcnt lgkmcnt(0) back to back: eight such stalls per RHS evaluation, 21 % of the
-// RK4 kernel's wave time parked in s_waitcnt (rocprofv3 SQ_WAIT_ANY).  The per-species and
-// equilibrium constants the RHS reads on every evaluation are therefore moved into VECTOR
-// registers once per kernel (an opaque v_mov, so the compiler can neither keep them scalar nor
-// re-load them); the kernels run one wave per SIMD and leave the AGPR half of the register file
-// idle, which is where the allocator parks them.  Values are unchanged: bit-identical results.
+// s_load + s_waitcnt lgkmcnt(0) back to back (eight such pairs per RHS evaluation before this
+// change).  The per-species constants the RHS reads on every evaluation are therefore moved into
+// VECTOR registers once per kernel (an opaque v_mov, so the compiler can neither keep them scalar
+// nor re-load them); the one-wave-per-SIMD kernels leave the AGPR half of the register file idle,
+// which is where the allocator parks them.  Worth 2 % on the 64k fan.  Values are unchanged:
+// bit-identical results.
 // ---------------------------------------------------------------------------------------------
 #ifdef RAYS_HOST_EMUL
 RAYS_DEV double in_vgpr(double x) { return x; }

@@ -1,0 +1,13 @@
+"""Wall time of the host-pointer entry rays_hip_trace (what the Fortran drop-in calls) on the 64k fan."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from rays_amd.trace import RaysRun
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+run = RaysRun.from_namelist(os.path.join(root, "configs/cfg3b_solovev64k_rk4.in"))
+for i in range(3):
+    t0 = time.perf_counter()
+    res = run.trace_rays(ngpu=1)
+    dt = time.perf_counter() - t0
+    print(f"call {i}: {dt*1e3:.1f} ms wall (incl. allocating/zeroing the 4.7 GB of host arrays in Python), "
+          f"library-reported {res.elapsed_s*1e3:.1f} ms, {res.total_steps} steps", flush=True)
