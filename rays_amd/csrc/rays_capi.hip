@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -477,6 +478,15 @@ static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1
   const int n = r1 - r0;
   if (n <= 0) return 0;
   const size_t npt = (size_t)p->nstep_max + 1, nv = (size_t)p->nv;
+  const bool timing = std::getenv("RAYS_HIP_TIMING") != nullptr;  // phase times of this entry on stderr
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[rays_hip_trace dev %d] %-28s %8.2f ms\n", dev, what,
+                 std::chrono::duration<double, std::milli>(now - t_prev).count());
+    t_prev = now;
+  };
   DEV_TRY(hipSetDevice(dev));
   hipStream_t st;
   DEV_TRY(hipStreamCreate(&st));
@@ -502,6 +512,7 @@ static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1
     DEV_CHK(hipMalloc(&d_ev, sizeof(double) * nv * n));
     DEV_CHK(hipMalloc(&d_er, sizeof(double) * n));
     DEV_CHK(hipMalloc(&d_mr, sizeof(double) * n));
+    lap("device allocations");
     DEV_CHK(hipMemcpyAsync(d_r, rvec0 + 3 * (size_t)r0, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
     DEV_CHK(hipMemcpyAsync(d_n, rindex_vec0 + 3 * (size_t)r0, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
     // no zero-fill of the device arrays: only recorded points are read back
@@ -519,6 +530,7 @@ static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1
     // 154-164), this entry leaves them as the caller passed them.
     DEV_CHK(hipMemcpyAsync(npoints + r0, d_np, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
     DEV_CHK(hipStreamSynchronize(st));
+    lap("inputs + trace kernel");
     {
       std::vector<long long> offs((size_t)n + 1);
       offs[0] = 0;
@@ -546,7 +558,7 @@ static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1
           const long long base = offs[c.a];
           const double* sv = sb->vec[c.buf];
           const double* sr = sb->res[c.buf];
-          const int nt = 8;
+          const int nt = 16;
           std::vector<std::thread> th;
           for (int t = 0; t < nt; t++)
             th.emplace_back([&, t]() {
@@ -586,6 +598,7 @@ static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1
         (void)hipEventDestroy(ev[1]);
       } while (0);
       (void)hipFree(d_off); (void)hipFree(d_pv); (void)hipFree(d_pr);
+      lap("pack + copy + host scatter");
       if (!ok) {
         rc = bail(fail("rays_hip_trace: packed device-to-host copy failed (out of memory?)"));
         break;
@@ -597,9 +610,11 @@ static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1
     if (max_residuals) DEV_CHK(hipMemcpyAsync(max_residuals + r0, d_mr, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     DEV_CHK(hipStreamSynchronize(st));
   } while (0);
+  lap("summaries");
   (void)hipFree(d_r); (void)hipFree(d_n); (void)hipFree(d_rv); (void)hipFree(d_res); (void)hipFree(d_np);
   (void)hipFree(d_sc); (void)hipFree(d_ev); (void)hipFree(d_er); (void)hipFree(d_mr);
   (void)hipStreamDestroy(st);
+  lap("device frees");
   return rc;
 #undef DEV_CHK
 #undef DEV_TRY
