@@ -23,7 +23,8 @@ program ref_dump_driver
     use rf_m, only : omgrf, k0, dispersion_resid_limit
     use ode_m, only : nv, ds, s_max, nstep_max, ode_stop
     use ray_init_m, only : nray, rvec0, rindex_vec0
-    use ray_results_m, only : ray_vec, residual, npoints, ray_stop_flag, end_ray_vec, initial_ray_power
+    use ray_results_m, only : ray_vec, residual, npoints, ray_stop_flag, end_ray_vec, initial_ray_power, &
+         & write_results_LD
     use deposition_profiles_m, only : initialize_deposition_profiles, calculate_deposition_profiles, &
          & bin_a_ray, profiles_1D, n_profiles
     use equilibrium_m, only : equilibrium, eq_point, equilib_model
@@ -115,6 +116,9 @@ program ref_dump_driver
     write(*,'(a,es16.8)') 'RAYS_REF trace_wall_s = ', wall
     write(*,'(a,i0)')     'RAYS_REF threads = ', omp_get_max_threads()
     write(*,'(a,es16.8)') 'RAYS_REF steps_per_s = ', real(total_steps, rkind)/wall
+
+    call get_environment_variable('RAYS_DUMP_RESULTS_LD', sval, status=stat)
+    if (stat == 0 .and. len_trim(sval) > 0) call write_results_LD   ! the reference's own run_results.<label>
 
     if (trim(fname) == 'none') stop
 

@@ -101,6 +101,22 @@ class RaysRun:
         out = hip.trace_host(self.params, self.rvec0, self.rindex_vec0, ngpu=ngpu)
         return RayResults(**out)
 
+    def finalize_run(self, res: RayResults, directory: str = ".", list_directed: bool = True, netcdf: bool = True):
+        """finalize_run.f90:20-28: write run_results.<run_label> (list-directed) and/or
+        run_results.<run_label>.nc from the results of this run (rays_amd/results.py)."""
+        import os
+
+        from . import results as rf
+
+        label = str((self.namelist or {}).get("diagnostics_list", {}).get("run_label", "")).strip()
+        rr = rf.RunResults(res, self.ray_pwr_wt, label)
+        base = os.path.join(directory, "run_results." + label)
+        if list_directed:
+            rf.write_results_LD(base, rr)
+        if netcdf:
+            rf.write_results_NC(base + ".nc", rr)
+        return rr
+
 
 class DeviceTrace:
     """Device-resident trace: inputs/outputs are torch CUDA tensors, launches are asynchronous on

@@ -44,10 +44,24 @@ CASES = [
 ]
 
 
+def results_file_fixture():
+    """tests/golden/run_results.gold_slab4_ld: the reference's own write_results_LD output
+    (ray_results_m.f90:365-420) for configs/gold_slab4_results_ld.in -- data for the writers of
+    rays_amd/results.py."""
+    with tempfile.TemporaryDirectory() as d:
+        shutil.copy(os.path.join(ROOT, "configs", "gold_slab4_results_ld.in"), os.path.join(d, "rays.in"))
+        env = dict(os.environ, RAYS_DUMP_FILE="none", RAYS_DUMP_RESULTS_LD="1")
+        subprocess.run([REF], cwd=d, env=env, check=True, stdout=subprocess.DEVNULL)
+        shutil.copy(os.path.join(d, "run_results.ld4"), os.path.join(ROOT, "tests", "golden", "run_results.gold_slab4_ld"))
+    print("run_results.gold_slab4_ld")
+
+
 def main():
     only = set(sys.argv[1:])  # optional: fixture names to (re)generate
     if not os.path.exists(REF):
         sys.exit("oracle/_ref/rays_ref_dump missing: run `bash oracle/build_ref.sh` first")
+    if not only or "run_results.gold_slab4_ld" in only:
+        results_file_fixture()
     for name, cfg, subset, stride, nprobe in CASES:
         if only and name not in only:
             continue

@@ -1,0 +1,123 @@
+"""CPU tier: the on-disk result files (rays_amd/results.py) against the reference's own
+write_results_LD output for configs/gold_slab4_results_ld.in (tests/golden/run_results.gold_slab4_ld,
+written by the reference binary: tests/golden/make_golden.py)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from rays_amd import results as R
+from rays_amd.namelist import read_namelist
+from rays_amd.params import params_from_namelist
+from rays_amd.ray_init import initialize_ray_init
+from tests.common import ROOT
+
+REF_LD = os.path.join(ROOT, "tests", "golden", "run_results.gold_slab4_ld")
+CFG = os.path.join(ROOT, "configs", "gold_slab4_results_ld.in")
+ARRAYS = ("npoints", "initial_ray_power", "end_ray_parameter", "end_residuals", "max_residuals",
+          "start_ray_vec", "end_ray_vec", "residual", "ray_vec")
+
+
+class _Image:
+    """the RayResults fields a RunResults is built from, taken from a parsed file"""
+
+    def __init__(self, d):
+        for k in ("ray_vec", "residual", "npoints", "end_ray_parameter", "end_residuals", "max_residuals",
+                  "ray_stop_flag", "start_ray_vec", "end_ray_vec"):
+            setattr(self, k, d[k])
+
+
+def _from_file(d):
+    return R.RunResults(_Image(d), d["initial_ray_power"], d["RAYS_run_label"], d["date_vector"],
+                        d["total_trace_time"], d["ray_trace_time"])
+
+
+def test_reader_parses_reference_file():
+    d = R.read_results_LD(REF_LD)
+    assert (d["RAYS_run_label"], d["number_of_rays"], d["max_number_of_points"], d["dim_v_vector"]) == ("ld4", 4, 31, 7)
+    np.testing.assert_array_equal(d["npoints"], [31] * 4)
+    assert d["ray_stop_flag"] == [" nstep > nstep_max".ljust(60)] * 4     # leading blank: ray_tracing.f90:152
+    assert d["ray_vec"].shape == (4, 31, 7) and d["residual"].shape == (4, 31)
+    np.testing.assert_array_equal(d["ray_vec"][:, 0, :], d["start_ray_vec"])
+    np.testing.assert_array_equal(d["ray_vec"][:, 30, :], d["end_ray_vec"])
+    np.testing.assert_array_equal(d["initial_ray_power"], [0.0625] * 4)  # weight divided by nray twice (App. A-11)
+
+
+def test_list_directed_reals_follow_the_reference_build():
+    """Tokens as amdflang writes them (values seen in reference files)."""
+    for x, t in [(-0.08, "-8.E-02"), (0.0, "0."), (-0.6, "-.6"), (0.0625, "6.25E-02"), (3556.8295290699893, "3556.8295290699893"),
+                 (1e15, "1.E+15"), (1e16, "1.E+16"), (100.0, "100."), (31.0, "31."), (0.1, ".1"), (1e-5, "1.E-05"),
+                 (5e-324, "5.E-324"), (1.7976931348623157e308, "1.7976931348623157E+308"), (999999999999999.9, "999999999999999.9"),
+                 (1.298845018062841e-02, "1.298845018062841E-02"), (float("inf"), "Inf"), (-float("inf"), "-Inf")]:
+        assert R.ld_real(x) == t
+    rng = np.random.default_rng(5)
+    v = rng.uniform(-1, 1, 4000) * 10.0 ** rng.integers(-300, 300, 4000)
+    for x in v:
+        assert float(R.ld_real(x)) == x
+
+
+def test_writer_reproduces_reference_file_layout_and_values(tmp_path):
+    d = R.read_results_LD(REF_LD)
+    out = str(tmp_path / "run_results.ld4")
+    R.write_results_LD(out, _from_file(d))
+    mine, ref = open(out).read().split("\n"), open(REF_LD).read().split("\n")
+    assert len(mine) == len(ref)
+    for a, b in zip(mine, ref):          # same records, same tokens per record, same widths
+        assert len(a) == len(b) and len(a.split()) == len(b.split())
+        for ta, tb in zip(a.split(), b.split()):
+            if ta != tb:                 # a last digit may differ (see rays_amd/results.py); the value may not
+                assert float(ta) == float(tb)
+    e = R.read_results_LD(out)
+    for k in ARRAYS + ("date_vector", "ray_trace_time"):
+        np.testing.assert_array_equal(e[k], d[k])
+    assert e["ray_stop_flag"] == d["ray_stop_flag"] and e["total_trace_time"] == d["total_trace_time"]
+
+
+def test_netcdf_file_has_the_reference_schema(tmp_path):
+    d = R.read_results_LD(REF_LD)
+    d["npoints"] = np.array([31, 12, 1, 20], dtype=np.int32)       # ragged: the file is cut to maxval(npoints)
+    r = _from_file(d)
+    r.max_number_of_points = 31
+    out = str(tmp_path / "run_results.ld4.nc")
+    R.write_results_NC(out, r)
+    assert open(out, "rb").read(4) == b"CDF\x01"                    # classic format (nf90_clobber)
+    from scipy.io import netcdf_file
+    with netcdf_file(out, "r", mmap=False) as f:
+        assert {k: v for k, v in f.dimensions.items()} == dict(number_of_rays=4, max_number_of_points=31, dim_v_vector=7, d8=8, d60=60)
+        want = dict(date_vector=("i", ("d8",)), ray_vec=("d", ("number_of_rays", "max_number_of_points", "dim_v_vector")),
+                    residual=("d", ("number_of_rays", "max_number_of_points")), npoints=("i", ("number_of_rays",)),
+                    initial_ray_power=("f", ("number_of_rays",)), ray_trace_time=("f", ("number_of_rays",)),
+                    end_residuals=("f", ("number_of_rays",)), max_residuals=("f", ("number_of_rays",)),
+                    end_ray_parameter=("f", ("number_of_rays",)), start_ray_vec=("f", ("number_of_rays", "dim_v_vector")),
+                    end_ray_vec=("f", ("number_of_rays", "dim_v_vector")), ray_stop_flag=("c", ("number_of_rays", "d60")),
+                    total_trace_time=("f", ()))
+        assert set(f.variables) == set(want)
+        for k, (t, dims) in want.items():
+            assert (f.variables[k].typecode(), f.variables[k].dimensions) == (t, dims), k
+    d["npoints"][0] = 17
+    r = _from_file(d)
+    R.write_results_NC(out, r)
+    n = R.read_results_NC(out)
+    assert n["max_number_of_points"] == 20 and n["ray_vec"].shape == (4, 20, 7)
+    np.testing.assert_array_equal(n["ray_vec"], d["ray_vec"][:, :20, :])
+    np.testing.assert_array_equal(n["residual"], d["residual"][:, :20])
+    np.testing.assert_array_equal(n["end_ray_vec"], d["end_ray_vec"].astype(np.float32))
+    assert n["ray_stop_flag"] == d["ray_stop_flag"] and n["RAYS_run_label"] == "ld4"
+
+
+def test_kernel_source_on_host_writes_the_reference_file(tmp_path):
+    """namelist -> ray launcher -> the product kernel source (host emulation) -> write_results_LD equals
+    the reference's file in every array (dates and wall times aside)."""
+    from rays_amd.trace import RayResults
+    from tests import emul_lib
+    nml = read_namelist(CFG)
+    p = params_from_namelist(nml, None)
+    r0, n0, w = initialize_ray_init(p, nml, None)
+    res = RayResults(**emul_lib.trace(p, r0, n0))
+    out = str(tmp_path / "run_results.ld4")
+    R.write_results_LD(out, R.RunResults(res, w, "ld4"))
+    mine, ref = R.read_results_LD(out), R.read_results_LD(REF_LD)
+    for k in ARRAYS:
+        np.testing.assert_array_equal(mine[k], ref[k], err_msg=k)
+    assert mine["ray_stop_flag"] == ref["ray_stop_flag"]

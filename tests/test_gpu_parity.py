@@ -182,3 +182,23 @@ def test_device_ray_init_all_evanescent_and_missing_rho_table():
     far.rindex_theta0, far.delta_rindex_theta = 5.0, 0.1     # |n_theta| >> 1 everywhere: evanescent
     with pytest.raises(hip.RaysHipError, match="No successful ray initializations"):
         hip.ray_init_host(p, far, nray_max)
+
+
+def test_result_files_equal_reference(tmp_path):
+    """namelist -> device trace -> finalize_run writes run_results.<label>; every array
+    in it equals the reference's own file for the same namelist (tests/golden/run_results.gold_slab4_ld)."""
+    import os
+    from rays_amd import results as R
+    from rays_amd.trace import RaysRun
+    from tests.common import ROOT
+    run = RaysRun.from_namelist(os.path.join(ROOT, "configs", "gold_slab4_results_ld.in"))
+    run.finalize_run(run.trace_rays(), str(tmp_path))
+    mine = R.read_results_LD(str(tmp_path / "run_results.ld4"))
+    ref = R.read_results_LD(os.path.join(ROOT, "tests", "golden", "run_results.gold_slab4_ld"))
+    for k in ("npoints", "initial_ray_power", "end_ray_parameter", "end_residuals", "max_residuals",
+              "start_ray_vec", "end_ray_vec", "residual", "ray_vec"):
+        np.testing.assert_array_equal(mine[k], ref[k], err_msg=k)
+    assert mine["ray_stop_flag"] == ref["ray_stop_flag"]
+    nc = R.read_results_NC(str(tmp_path / "run_results.ld4.nc"))
+    np.testing.assert_array_equal(nc["ray_vec"], ref["ray_vec"])
+    np.testing.assert_array_equal(nc["npoints"], ref["npoints"])
