@@ -41,6 +41,12 @@ CASES = [
     # tools/make_solovev_eqdsk.py) + splined density + parabolic Te + ECH damping; the fixture also
     # carries the host-built spline tables (RAYS_DUMP_AXISYM)
     ("gold_axisym64_eqdsk_damp_rk4", "gold_axisym64_eqdsk_damp_rk4.in", list(range(0, 64, 5)), 10, 120),
+    # the slab models cfg 1 does not touch: toroid By/Bz + parabolic n (libm pow) and Te, ray_param = 'arcl',
+    # integrate_eq_gradients (nv = 12) | sheared By + linear_2 Bz + Gaussian n + two ion species, SG with
+    # finite-difference dD | linear_2 n and Te (whose value and gradient disagree in the reference), RK4 numerical
+    ("gold_slab_toroid_parab_arcl_grad_rk4", "gold_slab_toroid_parab_arcl_grad_rk4.in", None, 30, 120),
+    ("gold_slab_shear_gauss_3spec_sg_num", "gold_slab_shear_gauss_3spec_sg_num.in", None, 0, 0),
+    ("gold_slab_lin2_rk4_num", "gold_slab_lin2_rk4_num.in", None, 25, 60),
 ]
 
 

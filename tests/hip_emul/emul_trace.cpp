@@ -12,16 +12,25 @@ RAYS_EMUL_DEFINE_GLOBALS
 #include "emul_dev_params.inc"
 #include "../../rays_amd/csrc/rays_fan_setup.inc"
 
-template <int EQ, int DERIV>
-static void run(int solver, int nv, const rays::DevParams& D, const rays::TraceArgs& A) {
+// Instantiated here: two species with nv = 7 | 8 for every equilibrium; for the slab also nv = 12 | 13
+// (integrate_eq_gradients) and three species (nv = 7).
+template <int EQ, int DERIV, int NS, int NV>
+static int run1(int solver, const rays::DevParams& D, const rays::TraceArgs& A) {
   threadIdx.x = 0; blockIdx.x = 0; blockDim.x = 1; gridDim.x = 1;
-  if (nv == 7) {
-    if (solver == 0) rays::rk4_trace_kernel<EQ, 2, DERIV, 7>(D, A);
-    else rays::sg_trace_kernel<EQ, 2, DERIV, 7>(D, A);
-  } else {
-    if (solver == 0) rays::rk4_trace_kernel<EQ, 2, DERIV, 8>(D, A);
-    else rays::sg_trace_kernel<EQ, 2, DERIV, 8>(D, A);
+  if (solver == 0) rays::rk4_trace_kernel<EQ, NS, DERIV, NV>(D, A);
+  else rays::sg_trace_kernel<EQ, NS, DERIV, NV>(D, A);
+  return 0;
+}
+template <int EQ, int DERIV>
+static int run(int solver, int ns, int nv, const rays::DevParams& D, const rays::TraceArgs& A) {
+  if (ns == 2 && nv == 7) return run1<EQ, DERIV, 2, 7>(solver, D, A);
+  if (ns == 2 && nv == 8) return run1<EQ, DERIV, 2, 8>(solver, D, A);
+  if constexpr ((EQ & 3) == 0) {
+    if (ns == 2 && nv == 12) return run1<EQ, DERIV, 2, 12>(solver, D, A);
+    if (ns == 2 && nv == 13) return run1<EQ, DERIV, 2, 13>(solver, D, A);
+    if (ns == 3 && nv == 7) return run1<EQ, DERIV, 3, 7>(solver, D, A);
   }
+  return 1;
 }
 
 static std::vector<double> g_zfun;
@@ -50,7 +59,6 @@ extern "C" int rays_emul_trace(const rays_params_t* p, int nray, const double* r
                                const double* rindex_vec0, double* ray_vec, double* residual,
                                int32_t* npoints, int32_t* stop_code, double* end_ray_vec,
                                double* end_residuals, double* max_residuals) {
-  if (p->nspec != 1 || (p->nv != 7 && p->nv != 8)) return 1;  // emulation instantiates NS = 2, nv = 7 | 8
   unsigned counter = 0;
   rays::TraceArgs A;
   A.nray = nray; A.rvec0 = rvec0; A.rindex_vec0 = rindex_vec0; A.ray_vec = ray_vec;
@@ -70,7 +78,7 @@ extern "C" int rays_emul_trace(const rays_params_t* p, int nray, const double* r
   }
   // same kernel selection as rays_capi.hip: find_kernel (EQ = model | kEqUnitExp)
   const int e = p->equilib_model | (unit_exponents(*p) ? rays::kEqUnitExp : 0), d = p->ray_deriv, s = p->ode_solver;
-#define RAYS_EMUL_CASE(E, D) if (e == E && d == D) run<E, D>(s, p->nv, D_, A); else
+#define RAYS_EMUL_CASE(E, D) if (e == E && d == D) return run<E, D>(s, p->nspec + 1, p->nv, D_, A); else
   const rays::DevParams& D_ = D;
   RAYS_EMUL_CASE(0, 0) RAYS_EMUL_CASE(0, 1) RAYS_EMUL_CASE(1, 0) RAYS_EMUL_CASE(1, 1) RAYS_EMUL_CASE(2, 0) RAYS_EMUL_CASE(2, 1)
   RAYS_EMUL_CASE(4, 0) RAYS_EMUL_CASE(4, 1) RAYS_EMUL_CASE(5, 0) RAYS_EMUL_CASE(5, 1) RAYS_EMUL_CASE(6, 0) RAYS_EMUL_CASE(6, 1)
@@ -82,11 +90,12 @@ extern "C" int rays_emul_trace(const rays_params_t* p, int nray, const double* r
 // Ray initialisation (rays_ray_init.hpp: fan_member) run sequentially in the reference's loop order.
 template <int EQ>
 static bool emul_member(const rays::DevParams& D, const rays::FanArgs& F, const double* rvec, int ia, int ib, double* ri) {
+  if constexpr (EQ == 0) if (D.nspec == 2) return rays::fan_member<EQ, 3>(D, F, rvec, ia, ib, ri);
   return rays::fan_member<EQ, 2>(D, F, rvec, ia, ib, ri);
 }
 extern "C" int rays_emul_ray_init(const rays_params_t* p, const rays_fan_t* fan, int nray_max, double* rvec0,
                                   double* rindex_vec0, int32_t* nray) {
-  if (p->nspec != 1) return 1;
+  if (p->nspec != 1 && !(p->nspec == 2 && p->equilib_model == 0)) return 1;
   rays::FanArgs F;
   std::vector<double> launch;
   int per_r = 0;
