@@ -18,6 +18,12 @@ RK4_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_num"
              "gold_slab_toroid_parab_arcl_grad_rk4", "gold_slab_lin2_rk4_num"]
 SG_CASES = ["gold_solovev64_sg_cold", "gold_solovev64_sg_num", "gold_solovev64_damp_sg",
             "gold_slab_shear_gauss_3spec_sg_num"]
+# Gaussian density (libm exp in the profile) differentiated numerically: deriv_num's differences of D
+# over 1e-6 offsets amplify an ulp of exp (ocml here, glibc in the reference) by ~1e8 at every RHS,
+# so every ray drifts at the reference's own noise floor.  Counts and stop flags are exact; the
+# trajectories are held to 1e-6 (observed 1.2e-7).  The same kernel source on the host (glibc exp) is
+# bit-identical (tests/test_cpu_kernel_emul.py).
+LIBM_PROFILE_TOL = {"gold_slab_shear_gauss_3spec_sg_num": 1e-6}
 
 
 @pytest.mark.parametrize("name", RK4_CASES)
@@ -36,7 +42,8 @@ def test_sg_matches_reference_golden(name):
     'equations stiff', 'ODE total error' and box exits; trajectories within 1e-10."""
     g, nml, p = load_golden(name)
     out = hip.trace_host(p, g["rvec0"], g["rindex_vec0"], ngpu=1)
-    worst = assert_matches_golden(out, g, p)
+    tol = LIBM_PROFILE_TOL.get(name, 1e-10)
+    worst = assert_matches_golden(out, g, p, rel_tol=tol, resid_atol=1e-12 if tol == 1e-10 else 1e-9)
     print(f"{name}: worst rel err vs reference {worst:.3e}")
 
 
@@ -55,7 +62,9 @@ def test_sg_full_fan_matches_oracle(name):
         per_ray = np.maximum(per_ray, (num / den).max(axis=1))
     nbit = int((np.abs(out["ray_vec"] - ora["ray_vec"]).max(axis=(1, 2)) == 0).sum())
     print(f"{name}: {nbit}/{len(per_ray)} rays bitwise, worst accumulated rel err {per_ray.max():.3e}")
-    if p.ray_deriv == 0:
+    if name in LIBM_PROFILE_TOL:
+        assert per_ray.max() <= LIBM_PROFILE_TOL[name]
+    elif p.ray_deriv == 0:
         assert per_ray.max() <= 1e-10
     else:
         # SG + finite-difference dD: the step-size update calls libm pow (ode_RAYS.f90:1222); a
