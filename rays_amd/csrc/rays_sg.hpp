@@ -439,7 +439,11 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
     for (int l = 0; l < NV; l++) win[l] = pc == PC_F2 ? pp[l] : (pc == PC_CHECK ? vst[l] : yy[l]);
     SG_PROF(1);  // init + phase vote
     if (act) rhs_eval<EQ, NS, DERIV, NV>(P, win, pc == PC_CHECK, resid, cs_flag, cs_stop, code, f);
+#ifdef RAYS_SG_PROFILE
+    SG_PROF(__popcll(__ballot(act)) <= 8 ? 15 : 2);  // RHS (slot 15: trips serving <= 8 lanes)
+#else
     SG_PROF(2);  // RHS
+#endif
 
     // ---- per-lane continuation -------------------------------------------------------------------
     int stop = 0;

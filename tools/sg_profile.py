@@ -8,7 +8,7 @@ from rays_amd import hip
 from rays_amd.trace import DeviceTrace
 NAMES = ["loop/refill", "init+vote", "RHS", "CHECK bookkeeping", "AFTER_F2", "AFTER_F3", "CRASH", "DE_BEGIN",
          "DE_TOP", "START_DONE", "COEF tail", "STOP+tail", "COEF coefficient block", "COEF scale+shift",
-         "COEF predictor", "-"]
+         "COEF predictor", "RHS, <= 8 lanes served"]
 for cfg, sym in (("configs/cfg5_axisym256k_sg_damp.in", "rays_debug_sg_profile_1_2_0_1"),
                  ("configs/cfg3_solovev64k_sg_num.in", "rays_debug_sg_profile_1_1_1_1")):
     nml, p, r0, n0 = bench.build_fan(cfg, 1)
