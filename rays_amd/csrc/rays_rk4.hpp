@@ -12,11 +12,13 @@
 // A new ray starts in stage 3 with w = v0 (`first`), which is exactly the reference's initial
 // check_save call (ray_tracing.f90:100) and also yields the first step's f1.
 //
-// Recorded points are written by their own lane, eight 8-byte stores per step (record_point).  An
-// earlier version staged 8 points per lane in LDS and flushed them as 512-byte runs per ray; the
-// kernel is bound by instruction issue, not by HBM, and the flush's ~500 issue
-// slots per step cost 12 % of the 64k-fan pass against 14 for the direct stores (measured:
-// 5.05 -> 4.49 ms; HBM write traffic per launch in profiles/).
+// Recorded points: the one-wave-per-SIMD kernel with nv = 7 passes them through a per-lane LDS window
+// and writes whole 64-byte sectors (PointWindow, rays_trace.hpp: HBM write traffic 1.06x the
+// algorithmic bytes for 1.3 % of the pass); the other builds store each point directly from its lane
+// (record_point: 2.1x the bytes through partly written sectors, no LDS).  The kernel is bound by
+// instruction issue, not by HBM, so what matters is the issue slots the recording
+// costs: ~50 per step for the window, 14 for direct stores, ~500 for an earlier cooperative flush of
+// 512-byte runs (12 % of the pass).  -DRAYS_RK4_DIRECT_STORES builds the kernel without the window.
 #pragma once
 
 #include "rays_trace.hpp"
@@ -28,7 +30,13 @@ namespace rays {
 template <int EQ, int NS, int DERIV, int NV>
 __global__ void __launch_bounds__(256)
 rk4_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
+#ifdef RAYS_RK4_DIRECT_STORES
+#define RAYS_RK4_USE_RING 0
+#else
+#define RAYS_RK4_USE_RING 1
+#endif
 #include "rays_rk4_body.inc"
+#undef RAYS_RK4_USE_RING
 }
 
 // Two waves per SIMD (<= 256 combined registers): from two waves' worth of rays on this build wins,
@@ -39,12 +47,20 @@ rk4_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
 template <int EQ, int NS, int DERIV, int NV>
 __global__ void __launch_bounds__(256, 2)
 rk4_trace_kernel_w2(const DevParams P_kernarg, const TraceArgs A_hot) {
+#define RAYS_RK4_USE_RING 0
 #include "rays_rk4_body.inc"
+#undef RAYS_RK4_USE_RING
 }
 #else
 template <int EQ, int NS, int DERIV, int NV>
 void rk4_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
+#ifdef RAYS_RK4_DIRECT_STORES
+#define RAYS_RK4_USE_RING 0
+#else
+#define RAYS_RK4_USE_RING 1
+#endif
 #include "rays_rk4_body.inc"
+#undef RAYS_RK4_USE_RING
 }
 #endif
 

@@ -10,8 +10,9 @@
 //   * a lane whose ray terminates pulls the next ray index from a global counter (lane refill),
 //     so a wave stays full while rays of very different length (99..380 steps in the Solovev
 //     fan) are in flight;
-//   * a recorded point is written by its lane straight into the reference layout
-//     ray_vec(nv, nstep_max+1, nray) / residual(nstep_max+1, nray) (ray_results_m.f90:44-46).
+//   * a recorded point is written by its lane into the reference layout
+//     ray_vec(nv, nstep_max+1, nray) / residual(nstep_max+1, nray) (ray_results_m.f90:44-46), directly
+//     (record_point) or through a per-lane LDS window that emits whole 64-byte sectors (PointWindow).
 #pragma once
 
 #include "rays_device.hpp"
@@ -60,5 +61,91 @@ RAYS_DEV void record_point(const TraceArgs& A, long long pt, const double v[NV],
   for (int c = 0; c < NV; c++) A.ray_vec[pt * NV + c] = v[c];
   A.residual[pt] = resid;
 }
+
+// ---- PointWindow: recorded points leave the chip as whole 64-byte sectors ------------------------
+// record_point's stores are 56 + 8 bytes per step and lane, to addresses no other lane shares.  The
+// L2 does not keep such a partly written sector until the lane's next step (9 us later) completes it:
+// it is written back in between, so HBM sees most sectors two or three times (tools/ubench/
+// store_pattern.hip: 2.4x the bytes; 2.1x measured in the RK4 kernel).  PointWindow holds a lane's
+// last recorded doubles in LDS and writes a sector only once all eight of its doubles exist.
+//
+// Sector boundaries are those of the global address, so they fall differently for every ray (a ray's
+// slab starts at ray * 56056 bytes): `phase` = the slab's offset into its sector, in doubles.  The
+// window is laid out in SECTOR coordinates: row u holds the double that goes to (sector-aligned)
+// g[u], where g = slab + 56*(k-1) - phase for the k-th group of eight points.  A point p of the group
+// therefore lands on rows 7*(p & 7) + phase + (0..6), i.e. 0..62; after the eighth point rows 0..55
+// are seven complete sectors, written with 16-byte stores from fixed rows, and rows 56..62 (the
+// doubles beyond the last boundary) move down to 0..6 as the next group's head.  residual(:) gets the
+// same treatment with one sector per group.  Only a ray's first sector (shared with the previous
+// ray's slab) and its last points go out as single doubles.  Rows are row-major over the block's
+// lanes: every LDS access is conflict free whatever row each lane is at.  NV = 7 only (nv = 8 records
+// are whole sectors already).
+#ifdef RAYS_HOST_EMUL
+typedef double* trace_lds_ptr;
+#else
+typedef __attribute__((address_space(3))) double* trace_lds_ptr;
+#endif
+struct alignas(16) SectorPair { double a, b; };
+
+struct PointWindow {
+  static constexpr int NV = 7, kPts = 8, kVecRows = 63, kResRows = 15;
+  static constexpr int kStride = 256;  // lanes per block
+  static constexpr size_t kLdsBytes = (size_t)(kVecRows + kResRows) * kStride * sizeof(double);
+  trace_lds_ptr vec, res;  // this lane's columns
+
+  RAYS_DEV void attach(double* lds, int lane_in_block) {
+    vec = (trace_lds_ptr)(lds + lane_in_block);
+    res = (trace_lds_ptr)(lds + (size_t)kVecRows * kStride + lane_in_block);
+  }
+  // offsets of ray's slabs into their sectors, in doubles (both < 8)
+  RAYS_DEV static void phases(const TraceArgs& A, int ray, long long npt, int& pv, int& pr) {
+    const unsigned bv = (unsigned)((unsigned long long)A.ray_vec >> 3), br = (unsigned)((unsigned long long)A.residual >> 3);
+    pv = (int)((bv + (unsigned)ray * (unsigned)((npt * NV) & 7)) & 7u);
+    pr = (int)((br + (unsigned)ray * (unsigned)(npt & 7)) & 7u);
+  }
+  RAYS_DEV void put(int pt, int pv, int pr, const double v[NV], double resid) {
+    const trace_lds_ptr p = vec + ((pt & 7) * NV + pv) * kStride;
+#pragma unroll
+    for (int c = 0; c < NV; c++) p[c * kStride] = v[c];
+    res[((pt & 7) + pr) * kStride] = resid;
+  }
+  // one sector from rows r0..r0+7 of col to g (64-byte aligned); `from` > 0: only elements >= from
+  RAYS_DEV static void sector(double* g, trace_lds_ptr col, int r0, int from) {
+    double e[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = col[(r0 + i) * kStride];
+    if (RAYS_RARE(from > 0)) {
+#pragma unroll
+      for (int i = 1; i < 8; i++)
+        if (i >= from) g[i] = e[i];
+    } else {
+      SectorPair* o = reinterpret_cast<SectorPair*>(g);
+#pragma unroll
+      for (int i = 0; i < 4; i++) o[i] = SectorPair{e[2 * i], e[2 * i + 1]};
+    }
+  }
+  // after the put of point 8k-1: write the group's complete sectors, keep the rest as the next head
+  RAYS_DEV void flush(const TraceArgs& A, long long pt0, int k, int pv, int pr) {
+    double* g = A.ray_vec + pt0 * NV + (56 * (k - 1) - pv);
+    sector(g, vec, 0, k == 1 ? pv : 0);  // a ray's first sector belongs in part to the ray before it
+#pragma unroll
+    for (int j = 1; j < 7; j++) sector(g + 8 * j, vec, 8 * j, 0);
+#pragma unroll
+    for (int i = 0; i < 7; i++) vec[i * kStride] = vec[(56 + i) * kStride];
+    sector(A.residual + pt0 + (8 * (k - 1) - pr), res, 0, k == 1 ? pr : 0);
+#pragma unroll
+    for (int i = 0; i < 7; i++) res[i * kStride] = res[(8 + i) * kStride];
+  }
+  // the ray ended with n points: write what the window still holds
+  RAYS_DEV void finish(const TraceArgs& A, long long pt0, int n, int pv, int pr) {
+    const int K = n >> 3, m = n & 7;
+    double* g = A.ray_vec + pt0 * NV + (56 * K - pv);
+#pragma nounroll
+    for (int u = K ? 0 : pv; u < pv + NV * m; u++) g[u] = vec[u * kStride];
+    double* gr = A.residual + pt0 + (8 * K - pr);
+#pragma nounroll
+    for (int u = K ? 0 : pr; u < pr + m; u++) gr[u] = res[u * kStride];
+  }
+};
 
 }  // namespace rays

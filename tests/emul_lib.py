@@ -91,12 +91,22 @@ def set_axisym_tables(tab: dict, small_tiers: bool = False):
     fn(C.byref(t))
 
 
-def trace(p: RaysParams, rvec0, rindex_vec0, small_tiers: bool = False) -> dict:
+def _offset_zeros(shape, offset):
+    """zeros of `shape` whose first element sits `offset` doubles past a 64-byte boundary"""
+    n = int(np.prod(shape))
+    raw = np.zeros(n + 16)
+    skew = (-(raw.ctypes.data // 8) + offset) % 8
+    return raw[skew:skew + n].reshape(shape)
+
+
+def trace(p: RaysParams, rvec0, rindex_vec0, small_tiers: bool = False, vec_offset: int = 0, res_offset: int = 0) -> dict:
+    """vec_offset / res_offset: position of the two trajectory arrays within a 64-byte sector, in doubles
+    (the RK4 kernel's PointWindow writes whole sectors of the global address)."""
     rvec0 = np.ascontiguousarray(rvec0, dtype=np.float64)
     rindex_vec0 = np.ascontiguousarray(rindex_vec0, dtype=np.float64)
     nray, nv, npt = len(rvec0), p.nv, p.nstep_max + 1
     out = dict(
-        ray_vec=np.zeros((nray, npt, nv)), residual=np.zeros((nray, npt)),
+        ray_vec=_offset_zeros((nray, npt, nv), vec_offset), residual=_offset_zeros((nray, npt), res_offset),
         npoints=np.zeros(nray, dtype=np.int32), stop_code=np.zeros(nray, dtype=np.int32),
         end_ray_vec=np.zeros((nray, nv)), end_residuals=np.zeros(nray), max_residuals=np.zeros(nray))
     d = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))

@@ -16,6 +16,29 @@ def test_kernel_source_on_host_equals_reference(name):
     assert_matches_golden(out, g, p, exact=True)
 
 
+@pytest.mark.parametrize("offsets", [(0, 0), (1, 7), (3, 4), (5, 2), (7, 1)])
+def test_rk4_point_window_any_sector_alignment(offsets):
+    """The RK4 kernel (nv = 7) passes recorded points through a per-lane window and writes whole 64-byte
+    sectors of the GLOBAL address (rays_trace.hpp: PointWindow); a ray's slab starts anywhere within a
+    sector.  Every placement of the two arrays must give the same trajectories, with nothing written
+    outside a ray's points (1024 rays: all per-ray phases, all tail lengths, rays that stop at once)."""
+    g, nml, p = load_golden("cfg2_solovev1024_rk4")
+    r0, n0 = g["rvec0_full"][:256].copy(), g["rindex_vec0_full"][:256].copy()
+    r0[5, 0] = 10.0     # launched outside the box: npoints = 1
+    n0[9] *= 3.0        # off the dispersion surface: stops at the initial check
+    ref = emul_lib.trace(p, r0, n0)
+    out = emul_lib.trace(p, r0, n0, vec_offset=offsets[0], res_offset=offsets[1])
+    for k in ("ray_vec", "residual", "npoints", "stop_code", "end_ray_vec"):
+        np.testing.assert_array_equal(out[k], ref[k])
+    assert ref["npoints"][5] == 1 and ref["npoints"][9] == 1
+    live = np.arange(p.nstep_max + 1)[None, :] < ref["npoints"][:, None]
+    assert not out["ray_vec"][~live].any() and not out["residual"][~live].any()
+    sub = [int(i) for i in g["ray_index"] if i < 256]
+    np.testing.assert_array_equal(out["npoints"][sub], g["npoints"][:len(sub)])
+    keep = g["ray_vec"].shape[1]
+    np.testing.assert_array_equal(out["ray_vec"][sub, :keep], g["ray_vec"][:len(sub)])
+
+
 @pytest.mark.parametrize("name", ["gold_solovev64_sg_cold", "gold_solovev64_sg_num", "gold_solovev64_damp_sg"])
 def test_sg_storage_tiers(name):
     """The SG kernel keeps its coefficient vectors and divided differences in tiers (LDS / registers
