@@ -203,6 +203,11 @@ def main():
             # pass i overlap the trace of pass i+1; barrier() below drains the last one
             tg.gather_async(tr.ray_vec, tr.residual, tr.npoints, tr.stop_code)
 
+        # one untimed exchange of the first pass: RCCL builds its point-to-point connections on first
+        # use, which must not land in the timed region when the caller asks for --warmup 0
+        gather()
+        tg.finish()
+
     deposit = None
     if args.exchange == "deposition":
         from rays_amd.exchange import ProfileChain
