@@ -39,6 +39,24 @@ def test_rk4_point_window_any_sector_alignment(offsets):
     np.testing.assert_array_equal(out["ray_vec"][sub, :keep], g["ray_vec"][:len(sub)])
 
 
+@pytest.mark.parametrize("nstep_max", [0, 1, 6, 7, 8, 9, 15, 16, 17, 64, 200])
+def test_rk4_point_window_group_boundaries(nstep_max):
+    """Rays ending before, on and after the window's eight-point groups (rays_trace.hpp: PointWindow),
+    against the C restatement, for two placements of the arrays within a sector."""
+    from rays_amd.params import copy_params
+    from tests import oracle_lib
+    g, nml, p = load_golden("cfg2_solovev1024_rk4")
+    r0, n0 = g["rvec0_full"][:96].copy(), g["rindex_vec0_full"][:96].copy()
+    r0[3, 0] = 10.0
+    q = copy_params(p)
+    q.nstep_max = nstep_max
+    ora = oracle_lib.trace(q, r0, n0)
+    for off in ((0, 0), (3, 5)):
+        out = emul_lib.trace(q, r0, n0, vec_offset=off[0], res_offset=off[1])
+        for k in ("ray_vec", "residual", "npoints", "stop_code", "end_ray_vec"):
+            np.testing.assert_array_equal(out[k], ora[k])   # NaN == NaN here (rays ending on 'infinite_Vg')
+
+
 @pytest.mark.parametrize("name", ["gold_solovev64_sg_cold", "gold_solovev64_sg_num", "gold_solovev64_damp_sg"])
 def test_sg_storage_tiers(name):
     """The SG kernel keeps its coefficient vectors and divided differences in tiers (LDS / registers
