@@ -207,7 +207,9 @@ int rays_hip_check_params(const rays_params_t* p);
  * ray_vec / residual: points 1..npoints(i) of every ray are written; entries beyond are left as the
  * caller passed them -- as in the reference, whose arrays are zero-filled by
  * initialize_ray_results_m (ray_results_m.f90:154-164) before trace_rays runs.  (Only the
- * recorded points cross PCIe: packed on the device, unpacked by host threads.)
+ * recorded points cross PCIe: packed on the device, unpacked by host threads.)  One caller thread at a
+ * time, like the reference's trace_rays; the entry keeps its device buffers, pinned staging and stream
+ * between calls until rays_hip_finalize().
  *   stop_code[nray]          integer image of ray_stop_flag(iray)          (ray_tracing.f90:258)
  *   end_ray_vec[nray][nv]    v at the last valid step                       (ray_tracing.f90:260)
  *   end_residuals[nray]      residual(nstep,iray)                           (ray_tracing.f90:255)

@@ -297,6 +297,7 @@ int rays_hip_init(int ngpu) {
   return ngpu;
 }
 
+static void release_cached_device_blocks();
 int rays_hip_finalize(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (size_t d = 0; d < g_ws.size(); d++)
@@ -305,6 +306,7 @@ int rays_hip_finalize(void) {
       (void)hipFree(g_ws[d].counters);
       g_ws[d].counters = nullptr;
     }
+  release_cached_device_blocks();
   g_devices.clear();
   return 0;
 }
@@ -428,6 +430,81 @@ int rays_hip_trace_device(const rays_params_t* p, int nray, const double* d_rvec
   return 0;
 }
 
+// Device buffers of rays_hip_trace are kept between calls (a host that traces repeatedly -- ray_scan, a
+// time loop -- otherwise pays ~6 ms per call for hipMalloc/hipFree of the 64k fan's 5 GB): a released
+// block goes to its device's free list and serves the next request of a similar size.  Everything is
+// returned to the driver by rays_hip_finalize, or at once when an allocation fails.
+struct DeviceBlockCache {
+  struct Block { void* p; size_t cap; };
+  std::mutex mu;
+  std::vector<Block> idle;
+  std::map<void*, size_t> live;
+  hipStream_t stream = nullptr;  // the entry's stream on this device (creating one costs ~8 ms per call)
+  void drop_idle() {  // caller holds mu and has the device current
+    for (auto& b : idle) (void)hipFree(b.p);
+    idle.clear();
+  }
+};
+static DeviceBlockCache g_blocks[16];
+static hipError_t cached_malloc(int dev, void** out, size_t bytes) {
+  if (dev < 0 || dev >= 16) return hipMalloc(out, bytes);
+  DeviceBlockCache& c = g_blocks[dev];
+  std::lock_guard<std::mutex> lk(c.mu);
+  size_t best = c.idle.size();
+  for (size_t i = 0; i < c.idle.size(); i++)
+    if (c.idle[i].cap >= bytes && c.idle[i].cap <= bytes + bytes / 4 + (1u << 20) &&
+        (best == c.idle.size() || c.idle[i].cap < c.idle[best].cap))
+      best = i;
+  if (best < c.idle.size()) {
+    *out = c.idle[best].p;
+    c.live[*out] = c.idle[best].cap;
+    c.idle.erase(c.idle.begin() + (long)best);
+    return hipSuccess;
+  }
+  hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+  if (e != hipSuccess) {  // give the idle blocks back and try once more
+    (void)hipGetLastError();
+    c.drop_idle();
+    e = hipMalloc(out, bytes ? bytes : 1);
+  }
+  if (e == hipSuccess) c.live[*out] = bytes ? bytes : 1;
+  return e;
+}
+static hipError_t cached_stream(int dev, hipStream_t* out, bool* owned) {
+  *owned = dev < 0 || dev >= 16;
+  if (*owned) return hipStreamCreate(out);
+  DeviceBlockCache& c = g_blocks[dev];
+  std::lock_guard<std::mutex> lk(c.mu);
+  if (!c.stream) {
+    hipError_t e = hipStreamCreate(&c.stream);
+    if (e != hipSuccess) return e;
+  }
+  *out = c.stream;
+  return hipSuccess;
+}
+static void cached_free(int dev, void* ptr) {
+  if (!ptr) return;
+  if (dev < 0 || dev >= 16) { (void)hipFree(ptr); return; }
+  DeviceBlockCache& c = g_blocks[dev];
+  std::lock_guard<std::mutex> lk(c.mu);
+  auto it = c.live.find(ptr);
+  if (it == c.live.end()) { (void)hipFree(ptr); return; }
+  c.idle.push_back({ptr, it->second});
+  c.live.erase(it);
+}
+
+static void release_cached_device_blocks() {
+  for (int d = 0; d < 16; d++) {
+    DeviceBlockCache& c = g_blocks[d];
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (c.idle.empty() && !c.stream) continue;
+    (void)hipSetDevice(d);
+    c.drop_idle();
+    if (c.stream) (void)hipStreamDestroy(c.stream);
+    c.stream = nullptr;
+  }
+}
+
 // Pinned staging for the packed device-to-host copy of rays_hip_trace: two buffers per device,
 // allocated once (pinning is slow) and kept.  `points` = trajectory points one buffer holds.
 struct StagingBuffers {
@@ -489,7 +566,9 @@ static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1
   };
   DEV_TRY(hipSetDevice(dev));
   hipStream_t st;
-  DEV_TRY(hipStreamCreate(&st));
+  bool own_stream = false;
+  DEV_TRY(cached_stream(dev, &st, &own_stream));
+  lap("stream");
   double *d_r = nullptr, *d_n = nullptr, *d_rv = nullptr, *d_res = nullptr, *d_ev = nullptr, *d_er = nullptr,
          *d_mr = nullptr;
   int32_t *d_np = nullptr, *d_sc = nullptr;
@@ -503,15 +582,15 @@ static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1
       break;                                 \
     }                                        \
   }
-    DEV_CHK(hipMalloc(&d_r, sizeof(double) * 3 * n));
-    DEV_CHK(hipMalloc(&d_n, sizeof(double) * 3 * n));
-    DEV_CHK(hipMalloc(&d_rv, sizeof(double) * npt * nv * n));
-    DEV_CHK(hipMalloc(&d_res, sizeof(double) * npt * n));
-    DEV_CHK(hipMalloc(&d_np, sizeof(int32_t) * n));
-    DEV_CHK(hipMalloc(&d_sc, sizeof(int32_t) * n));
-    DEV_CHK(hipMalloc(&d_ev, sizeof(double) * nv * n));
-    DEV_CHK(hipMalloc(&d_er, sizeof(double) * n));
-    DEV_CHK(hipMalloc(&d_mr, sizeof(double) * n));
+    DEV_CHK(cached_malloc(dev, (void**)&d_r, sizeof(double) * 3 * n));
+    DEV_CHK(cached_malloc(dev, (void**)&d_n, sizeof(double) * 3 * n));
+    DEV_CHK(cached_malloc(dev, (void**)&d_rv, sizeof(double) * npt * nv * n));
+    DEV_CHK(cached_malloc(dev, (void**)&d_res, sizeof(double) * npt * n));
+    DEV_CHK(cached_malloc(dev, (void**)&d_np, sizeof(int32_t) * n));
+    DEV_CHK(cached_malloc(dev, (void**)&d_sc, sizeof(int32_t) * n));
+    DEV_CHK(cached_malloc(dev, (void**)&d_ev, sizeof(double) * nv * n));
+    DEV_CHK(cached_malloc(dev, (void**)&d_er, sizeof(double) * n));
+    DEV_CHK(cached_malloc(dev, (void**)&d_mr, sizeof(double) * n));
     lap("device allocations");
     DEV_CHK(hipMemcpyAsync(d_r, rvec0 + 3 * (size_t)r0, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
     DEV_CHK(hipMemcpyAsync(d_n, rindex_vec0 + 3 * (size_t)r0, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
@@ -538,12 +617,12 @@ static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1
       const long long total = offs[n];
       long long* d_off = nullptr;
       double *d_pv = nullptr, *d_pr = nullptr;
-      DEV_CHK(hipMalloc(&d_off, sizeof(long long) * ((size_t)n + 1)));
+      DEV_CHK(cached_malloc(dev, (void**)&d_off, sizeof(long long) * ((size_t)n + 1)));
       bool ok = true;
       do {
         if (total == 0) break;
-        if (hipMalloc(&d_pv, sizeof(double) * nv * (size_t)total) != hipSuccess ||
-            hipMalloc(&d_pr, sizeof(double) * (size_t)total) != hipSuccess) { ok = false; break; }
+        if (cached_malloc(dev, (void**)&d_pv, sizeof(double) * nv * (size_t)total) != hipSuccess ||
+            cached_malloc(dev, (void**)&d_pr, sizeof(double) * (size_t)total) != hipSuccess) { ok = false; break; }
         if (hipMemcpyAsync(d_off, offs.data(), sizeof(long long) * ((size_t)n + 1), hipMemcpyHostToDevice, st) != hipSuccess) { ok = false; break; }
         if (rays::launch_pack(true, n, (int)nv, p->nstep_max, d_np, d_off, d_rv, d_res, d_pv, d_pr, st) != hipSuccess) { ok = false; break; }
         StagingBuffers* sb = staging_for_device(dev, nv);
@@ -597,7 +676,7 @@ static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1
         (void)hipEventDestroy(ev[0]);
         (void)hipEventDestroy(ev[1]);
       } while (0);
-      (void)hipFree(d_off); (void)hipFree(d_pv); (void)hipFree(d_pr);
+      cached_free(dev, d_off); cached_free(dev, d_pv); cached_free(dev, d_pr);
       lap("pack + copy + host scatter");
       if (!ok) {
         rc = bail(fail("rays_hip_trace: packed device-to-host copy failed (out of memory?)"));
@@ -611,9 +690,9 @@ static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1
     DEV_CHK(hipStreamSynchronize(st));
   } while (0);
   lap("summaries");
-  (void)hipFree(d_r); (void)hipFree(d_n); (void)hipFree(d_rv); (void)hipFree(d_res); (void)hipFree(d_np);
-  (void)hipFree(d_sc); (void)hipFree(d_ev); (void)hipFree(d_er); (void)hipFree(d_mr);
-  (void)hipStreamDestroy(st);
+  cached_free(dev, d_r); cached_free(dev, d_n); cached_free(dev, d_rv); cached_free(dev, d_res); cached_free(dev, d_np);
+  cached_free(dev, d_sc); cached_free(dev, d_ev); cached_free(dev, d_er); cached_free(dev, d_mr);
+  if (own_stream) (void)hipStreamDestroy(st);
   lap("device frees");
   return rc;
 #undef DEV_CHK

@@ -192,8 +192,11 @@ def deposition_device(p: RaysParams, which: str, n_bins: int, nray: int, d_ray_v
            "rays_hip_deposition_device")
 
 
-def trace_host(p: RaysParams, rvec0, rindex_vec0, ngpu: int = 0) -> dict:
-    """rays_hip_trace: host numpy arrays in / out (the Fortran drop-in entry)."""
+def trace_host(p: RaysParams, rvec0, rindex_vec0, ngpu: int = 0, out: dict = None) -> dict:
+    """rays_hip_trace: host numpy arrays in / out (the Fortran drop-in entry).  `out`: the result
+    arrays of an earlier call over the same fan to write into (the library overwrites points
+    1..npoints only, so they must hold zeros or an earlier result of the same fan -- the Fortran host's
+    situation, whose arrays are allocated and zero-filled once by initialize_ray_results_m)."""
     lib = load()
     rvec0 = np.ascontiguousarray(rvec0, dtype=np.float64)
     rindex_vec0 = np.ascontiguousarray(rindex_vec0, dtype=np.float64)
@@ -201,10 +204,13 @@ def trace_host(p: RaysParams, rvec0, rindex_vec0, ngpu: int = 0) -> dict:
     if lib.rays_hip_init(int(ngpu)) < 0:
         raise RaysHipError("rays_hip_init: " + last_error())
     ensure_tables(p)
-    out = dict(
-        ray_vec=np.zeros((nray, npt, nv)), residual=np.zeros((nray, npt)),
-        npoints=np.zeros(nray, dtype=np.int32), stop_code=np.zeros(nray, dtype=np.int32),
-        end_ray_vec=np.zeros((nray, nv)), end_residuals=np.zeros(nray), max_residuals=np.zeros(nray))
+    if out is None:
+        out = dict(
+            ray_vec=np.zeros((nray, npt, nv)), residual=np.zeros((nray, npt)),
+            npoints=np.zeros(nray, dtype=np.int32), stop_code=np.zeros(nray, dtype=np.int32),
+            end_ray_vec=np.zeros((nray, nv)), end_residuals=np.zeros(nray), max_residuals=np.zeros(nray))
+    elif out["ray_vec"].shape != (nray, npt, nv) or not out["ray_vec"].flags.c_contiguous:
+        raise ValueError("trace_host: `out` does not match this fan")
     el = C.c_double(0.0)
     rc = lib.rays_hip_trace(C.byref(p), nray, _dp(rvec0), _dp(rindex_vec0), _dp(out["ray_vec"]),
                             _dp(out["residual"]), _ip(out["npoints"]), _ip(out["stop_code"]),

@@ -11,3 +11,12 @@ for i in range(3):
     dt = time.perf_counter() - t0
     print(f"call {i}: {dt*1e3:.1f} ms wall (incl. allocating/zeroing the 4.7 GB of host arrays in Python), "
           f"library-reported {res.elapsed_s*1e3:.1f} ms, {res.total_steps} steps", flush=True)
+
+# the Fortran host's situation: result arrays allocated and zero-filled once, pages resident
+from rays_amd import hip
+out = hip.trace_host(run.params, run.rvec0, run.rindex_vec0, ngpu=1)
+for i in range(3):
+    t0 = time.perf_counter()
+    out = hip.trace_host(run.params, run.rvec0, run.rindex_vec0, ngpu=1, out=out)
+    dt = time.perf_counter() - t0
+    print(f"resident arrays, call {i}: {dt*1e3:.1f} ms wall, library-reported {out['elapsed_s']*1e3:.1f} ms", flush=True)
