@@ -51,6 +51,20 @@ def test_rays_that_never_start_and_limits():
     assert (out["stop_code"][[0, 1, 2]] == 1).all() and (out["npoints"][[0, 1, 2]] == 11).all()
 
 
+@pytest.mark.parametrize("nstep_max", [6, 7, 8, 9, 16, 65])
+def test_point_window_group_boundaries(nstep_max):
+    """The RK4 kernel's LDS point window (rays_trace.hpp: PointWindow) with rays ending before, on and
+    after its eight-point groups; 1024 rays cover every sector phase of ray_vec and residual."""
+    g, nml, p = load_golden("cfg2_solovev1024_rk4")
+    q = copy_params(p)
+    q.nstep_max = nstep_max
+    r0, n0 = g["rvec0_full"].copy(), g["rindex_vec0_full"].copy()
+    r0[3, 0] = 10.0
+    out, ora = hip.trace_host(q, r0, n0, ngpu=1), oracle_lib.trace(q, r0, n0)
+    for k in ("ray_vec", "residual", "npoints", "stop_code", "end_ray_vec"):
+        np.testing.assert_array_equal(out[k], ora[k])
+
+
 def test_arcl_parameter_and_eq_gradients():
     """ray_param = 'arcl' and integrate_eq_gradients (nv = 12): v(7) tracks s, gradient rows track B."""
     g, nml, p = load_golden("cfg2_solovev1024_rk4")
