@@ -31,12 +31,12 @@ template <int EQ, int NS, int DERIV, int NV>
 __global__ void __launch_bounds__(256)
 rk4_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
 #ifdef RAYS_RK4_DIRECT_STORES
-#define RAYS_RK4_USE_RING 0
+#define RAYS_RK4_USE_WINDOW 0
 #else
-#define RAYS_RK4_USE_RING 1
+#define RAYS_RK4_USE_WINDOW 1
 #endif
 #include "rays_rk4_body.inc"
-#undef RAYS_RK4_USE_RING
+#undef RAYS_RK4_USE_WINDOW
 }
 
 // Two waves per SIMD (<= 256 combined registers): from two waves' worth of rays on this build wins,
@@ -47,20 +47,20 @@ rk4_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
 template <int EQ, int NS, int DERIV, int NV>
 __global__ void __launch_bounds__(256, 2)
 rk4_trace_kernel_w2(const DevParams P_kernarg, const TraceArgs A_hot) {
-#define RAYS_RK4_USE_RING 0
+#define RAYS_RK4_USE_WINDOW 0
 #include "rays_rk4_body.inc"
-#undef RAYS_RK4_USE_RING
+#undef RAYS_RK4_USE_WINDOW
 }
 #else
 template <int EQ, int NS, int DERIV, int NV>
 void rk4_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
 #ifdef RAYS_RK4_DIRECT_STORES
-#define RAYS_RK4_USE_RING 0
+#define RAYS_RK4_USE_WINDOW 0
 #else
-#define RAYS_RK4_USE_RING 1
+#define RAYS_RK4_USE_WINDOW 1
 #endif
 #include "rays_rk4_body.inc"
-#undef RAYS_RK4_USE_RING
+#undef RAYS_RK4_USE_WINDOW
 }
 #endif
 
