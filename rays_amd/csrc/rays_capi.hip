@@ -122,7 +122,9 @@ const rays::KernelEntry* find_kernel(const rays_params_t& p, long long nray = 0)
     if (nray > 0 && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
       ncu = prop.multiProcessorCount;
   }
-  const bool big = nray >= 2ll * ncu * 256;  // >= two waves per SIMD
+  bool big = nray >= 2ll * ncu * 256;  // >= two waves per SIMD
+  if (const char* f = std::getenv("RAYS_HIP_FORCE_WAVES_PER_SIMD"))  // developer measurement: "1" | "2"
+    big = f[0] == '2';
   const KernelEntry* found = nullptr;
   for (int i = 0; i < n; i++)
     if (e[i].ns == p.nspec + 1 && e[i].nv == p.nv) {
