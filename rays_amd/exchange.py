@@ -78,19 +78,6 @@ class TrajectoryGather:
         self._pending = None
         self._buf = 0
 
-    # The packed trajectory block of a rank (0.7 GB for a 64k-ray fan) goes out as kPieces operations of
-    # the one group rather than as a single message: RCCL spreads the operations between a pair of ranks
-    # over its channels, and a peer's link to the root is the resource to fill.  Both sides cut the same
-    # [points][nv] buffer (its length is known to both from prepare()) by the same rule.
-    kPieces = 8
-
-    def _pieces(self, buf):
-        n = buf.shape[0]
-        if n < 8 * self.kPieces:
-            return [buf]
-        step = (n + self.kPieces - 1) // self.kPieces
-        return [buf[i:i + step] for i in range(0, n, step)]
-
     def _stream(self):
         t = self.torch
         return t.cuda.current_stream().cuda_stream if self.device.type == "cuda" else 0
@@ -158,15 +145,15 @@ class TrajectoryGather:
                     continue
                 rc = self._recv[b][r]
                 ops += [dist.P2POp(dist.irecv, rc["npoints"], r, self.group),
-                        dist.P2POp(dist.irecv, rc["stop"], r, self.group)]
-                ops += [dist.P2POp(dist.irecv, piece, r, self.group) for piece in self._pieces(rc["vec"])]
-                ops += [dist.P2POp(dist.irecv, rc["res"], r, self.group)]
+                        dist.P2POp(dist.irecv, rc["stop"], r, self.group),
+                        dist.P2POp(dist.irecv, rc["vec"], r, self.group),
+                        dist.P2POp(dist.irecv, rc["res"], r, self.group)]
             works = dist.batch_isend_irecv(ops) if ops else []
         elif n_local > 0:
             ops = [dist.P2POp(dist.isend, snd["npoints"], 0, self.group),
-                   dist.P2POp(dist.isend, snd["stop"], 0, self.group)]
-            ops += [dist.P2POp(dist.isend, piece, 0, self.group) for piece in self._pieces(snd["vec"])]
-            ops += [dist.P2POp(dist.isend, snd["res"], 0, self.group)]
+                   dist.P2POp(dist.isend, snd["stop"], 0, self.group),
+                   dist.P2POp(dist.isend, snd["vec"], 0, self.group),
+                   dist.P2POp(dist.isend, snd["res"], 0, self.group)]
             works = dist.batch_isend_irecv(ops)
         self._pending = (b, works)
         self._buf = 1 - b
