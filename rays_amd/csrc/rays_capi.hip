@@ -101,7 +101,7 @@ const FlagText kFlags[] = {
     {RAYS_STOP_SG_EPS_LE_0, "eps <= 0"},
 };
 
-static_assert(rays::kBlock == rays::PointWindow::kStride, "PointWindow rows are laid out for the launch block size");
+static_assert(rays::kBlock == rays::PointWindow<7>::kStride, "PointWindow rows are laid out for the launch block size");
 #include "rays_dev_params.inc"
 
 // nray: fan size (0 = unknown).  From two waves per SIMD worth of rays on, the two-waves-per-SIMD build

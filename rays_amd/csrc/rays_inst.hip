@@ -39,7 +39,7 @@ hipError_t launch_one(const DevParams& P, const TraceArgs& A, hipStream_t stream
 #ifdef RAYS_RK4_DIRECT_STORES
   constexpr size_t lds = 0;
 #else
-  constexpr size_t lds = NV == PointWindow::NV ? PointWindow::kLdsBytes : 0;  // rays_trace.hpp
+  constexpr size_t lds = PointWindow<NV>::kLdsBytes;  // rays_trace.hpp (0 unless nv = 7 | 8)
 #endif
   return launch_persistent(rk4_trace_kernel<EQ, NS, DERIV, NV>, lds, P, A, stream, grid_blocks);
 #else

@@ -14,7 +14,8 @@
 //
 // Recorded points: the one-wave-per-SIMD kernel with nv = 7 passes them through a per-lane LDS window
 // and writes whole 64-byte sectors (PointWindow, rays_trace.hpp: HBM write traffic 1.06x the
-// algorithmic bytes for 1.3 % of the pass); the other builds store each point directly from its lane
+// algorithmic bytes for 1.3 % of the pass; with nv = 8 only residual(:) needs it, a ray_vec record being
+// one sector); the other builds store each point directly from its lane
 // (record_point: 2.1x the bytes through partly written sectors, no LDS).  The kernel is bound by
 // instruction issue, not by HBM, so what matters is the issue slots the recording
 // costs: ~50 per step for the window, 14 for direct stores, ~500 for an earlier cooperative flush of

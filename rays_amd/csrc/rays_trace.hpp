@@ -78,8 +78,7 @@ RAYS_DEV void record_point(const TraceArgs& A, long long pt, const double v[NV],
 // doubles beyond the last boundary) move down to 0..6 as the next group's head.  residual(:) gets the
 // same treatment with one sector per group.  Only a ray's first sector (shared with the previous
 // ray's slab) and its last points go out as single doubles.  Rows are row-major over the block's
-// lanes: every LDS access is conflict free whatever row each lane is at.  NV = 7 only (nv = 8 records
-// are whole sectors already).
+// lanes: every LDS access is conflict free whatever row each lane is at.
 #ifdef RAYS_HOST_EMUL
 typedef double* trace_lds_ptr;
 #else
@@ -87,8 +86,12 @@ typedef __attribute__((address_space(3))) double* trace_lds_ptr;
 #endif
 struct alignas(16) SectorPair { double a, b; };
 
+// NV = 7: both streams pass through the window.  NV = 8: a ray_vec record IS one sector (the slabs are
+// 64-byte aligned when the array is), so only residual(:) does.  Other NV: no window (kAny = false).
+template <int NV>
 struct PointWindow {
-  static constexpr int NV = 7, kPts = 8, kVecRows = 63, kResRows = 15;
+  static constexpr bool kVec = NV == 7, kRes = NV == 7 || NV == 8, kAny = kRes;
+  static constexpr int kVecRows = kVec ? 63 : 0, kResRows = kRes ? 15 : 0;
   static constexpr int kStride = 256;  // lanes per block
   static constexpr size_t kLdsBytes = (size_t)(kVecRows + kResRows) * kStride * sizeof(double);
   trace_lds_ptr vec, res;  // this lane's columns
@@ -103,10 +106,16 @@ struct PointWindow {
     pv = (int)((bv + (unsigned)ray * (unsigned)((npt * NV) & 7)) & 7u);
     pr = (int)((br + (unsigned)ray * (unsigned)(npt & 7)) & 7u);
   }
-  RAYS_DEV void put(int pt, int pv, int pr, const double v[NV], double resid) {
-    const trace_lds_ptr p = vec + ((pt & 7) * NV + pv) * kStride;
+  // point pt of the ray whose slabs start at point index pt0
+  RAYS_DEV void put(const TraceArgs& A, long long pt0, int pt, int pv, int pr, const double v[NV], double resid) {
+    if constexpr (kVec) {
+      const trace_lds_ptr p = vec + ((pt & 7) * NV + pv) * kStride;
 #pragma unroll
-    for (int c = 0; c < NV; c++) p[c * kStride] = v[c];
+      for (int c = 0; c < NV; c++) p[c * kStride] = v[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < NV; c++) A.ray_vec[(pt0 + pt) * NV + c] = v[c];
+    }
     res[((pt & 7) + pr) * kStride] = resid;
   }
   // one sector from rows r0..r0+7 of col to g (64-byte aligned); `from` > 0: only elements >= from
@@ -126,12 +135,14 @@ struct PointWindow {
   }
   // after the put of point 8k-1: write the group's complete sectors, keep the rest as the next head
   RAYS_DEV void flush(const TraceArgs& A, long long pt0, int k, int pv, int pr) {
-    double* g = A.ray_vec + pt0 * NV + (56 * (k - 1) - pv);
-    sector(g, vec, 0, k == 1 ? pv : 0);  // a ray's first sector belongs in part to the ray before it
+    if constexpr (kVec) {
+      double* g = A.ray_vec + pt0 * NV + (56 * (k - 1) - pv);
+      sector(g, vec, 0, k == 1 ? pv : 0);  // a ray's first sector belongs in part to the ray before it
 #pragma unroll
-    for (int j = 1; j < 7; j++) sector(g + 8 * j, vec, 8 * j, 0);
+      for (int j = 1; j < 7; j++) sector(g + 8 * j, vec, 8 * j, 0);
 #pragma unroll
-    for (int i = 0; i < 7; i++) vec[i * kStride] = vec[(56 + i) * kStride];
+      for (int i = 0; i < 7; i++) vec[i * kStride] = vec[(56 + i) * kStride];
+    }
     sector(A.residual + pt0 + (8 * (k - 1) - pr), res, 0, k == 1 ? pr : 0);
 #pragma unroll
     for (int i = 0; i < 7; i++) res[i * kStride] = res[(8 + i) * kStride];
@@ -139,9 +150,11 @@ struct PointWindow {
   // the ray ended with n points: write what the window still holds
   RAYS_DEV void finish(const TraceArgs& A, long long pt0, int n, int pv, int pr) {
     const int K = n >> 3, m = n & 7;
-    double* g = A.ray_vec + pt0 * NV + (56 * K - pv);
+    if constexpr (kVec) {
+      double* g = A.ray_vec + pt0 * NV + (56 * K - pv);
 #pragma nounroll
-    for (int u = K ? 0 : pv; u < pv + NV * m; u++) g[u] = vec[u * kStride];
+      for (int u = K ? 0 : pv; u < pv + NV * m; u++) g[u] = vec[u * kStride];
+    }
     double* gr = A.residual + pt0 + (8 * K - pr);
 #pragma nounroll
     for (int u = K ? 0 : pr; u < pr + m; u++) gr[u] = res[u * kStride];
