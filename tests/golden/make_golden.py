@@ -41,6 +41,8 @@ CASES = [
     # tools/make_solovev_eqdsk.py) + splined density + parabolic Te + ECH damping; the fixture also
     # carries the host-built spline tables (RAYS_DUMP_AXISYM)
     ("gold_axisym64_eqdsk_damp_rk4", "gold_axisym64_eqdsk_damp_rk4.in", list(range(0, 64, 5)), 10, 120),
+    # the same with the Shampine-Gordon integrator: BASELINE config 5's kernel
+    ("gold_axisym64_eqdsk_damp_sg", "gold_axisym64_eqdsk_damp_sg.in", list(range(0, 64, 5)), 0, 0),
     # the slab models cfg 1 does not touch: toroid By/Bz + parabolic n (libm pow) and Te, ray_param = 'arcl',
     # integrate_eq_gradients (nv = 12) | sheared By + linear_2 Bz + Gaussian n + two ion species, SG with
     # finite-difference dD | linear_2 n and Te (whose value and gradient disagree in the reference), RK4 numerical
