@@ -43,6 +43,8 @@ CASES = [
     ("gold_axisym64_eqdsk_damp_rk4", "gold_axisym64_eqdsk_damp_rk4.in", list(range(0, 64, 5)), 10, 120),
     # the same with the Shampine-Gordon integrator: BASELINE config 5's kernel
     ("gold_axisym64_eqdsk_damp_sg", "gold_axisym64_eqdsk_damp_sg.in", list(range(0, 64, 5)), 0, 0),
+    # parabolic density with non-unit exponents (pow), splined Te and Ti, finite-difference dD
+    ("gold_axisym64_eqdsk_tspline_rk4_num", "gold_axisym64_eqdsk_tspline_rk4_num.in", list(range(0, 64, 5)), 10, 60),
     # the slab models cfg 1 does not touch: toroid By/Bz + parabolic n (libm pow) and Te, ray_param = 'arcl',
     # integrate_eq_gradients (nv = 12) | sheared By + linear_2 Bz + Gaussian n + two ion species, SG with
     # finite-difference dD | linear_2 n and Te (whose value and gradient disagree in the reference), RK4 numerical

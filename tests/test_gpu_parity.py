@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 RK4_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_num", "gold_solovev64_pow_rk4",
              "gold_solovev_evanescent_rk4",
              "gold_solovev64_damp_rk4", "gold_axisym64_eqdsk_damp_rk4",
-             "gold_slab_toroid_parab_arcl_grad_rk4", "gold_slab_lin2_rk4_num"]
+             "gold_slab_toroid_parab_arcl_grad_rk4", "gold_slab_lin2_rk4_num",
+             "gold_axisym64_eqdsk_tspline_rk4_num"]
 SG_CASES = ["gold_solovev64_sg_cold", "gold_solovev64_sg_num", "gold_solovev64_damp_sg", "gold_axisym64_eqdsk_damp_sg",
             "gold_slab_shear_gauss_3spec_sg_num"]
 # Gaussian density (libm exp in the profile) differentiated numerically: deriv_num's differences of D
@@ -23,14 +24,17 @@ SG_CASES = ["gold_solovev64_sg_cold", "gold_solovev64_sg_num", "gold_solovev64_d
 # so every ray drifts at the reference's own noise floor.  Counts and stop flags are exact; the
 # trajectories are held to 1e-6 (observed 1.2e-7).  The same kernel source on the host (glibc exp) is
 # bit-identical (tests/test_cpu_kernel_emul.py).
-LIBM_PROFILE_TOL = {"gold_slab_shear_gauss_3spec_sg_num": 1e-6}
+LIBM_PROFILE_TOL = {"gold_slab_shear_gauss_3spec_sg_num": 1e-6,
+                    # parabolic density with exponents 1.5 / 2 (libm pow) under deriv_num, same mechanism
+                    "gold_axisym64_eqdsk_tspline_rk4_num": 1e-6}
 
 
 @pytest.mark.parametrize("name", RK4_CASES)
 def test_rk4_matches_reference_golden(name):
     g, nml, p = load_golden(name)
     out = hip.trace_host(p, g["rvec0"], g["rindex_vec0"], ngpu=1)
-    worst = assert_matches_golden(out, g, p)
+    tol = LIBM_PROFILE_TOL.get(name, 1e-10)
+    worst = assert_matches_golden(out, g, p, rel_tol=tol, resid_atol=1e-12 if tol == 1e-10 else 1e-9)
     keep = g["ray_vec"].shape[1]
     print(f"{name}: worst rel err vs reference {worst:.3e}; ray_vec bitwise: "
           f"{np.array_equal(out['ray_vec'][:, :keep], g['ray_vec'])}")
@@ -125,7 +129,11 @@ def test_device_ray_init_matches_reference(name):
     fan, nray_max = fan_from_namelist(nml)
     r0, n0, w = hip.ray_init_host(p, fan, nray_max)
     np.testing.assert_array_equal(r0, g["rvec0_full"])
-    np.testing.assert_array_equal(n0, g["rindex_vec0_full"])
+    if name in LIBM_PROFILE_TOL and p.equilib_model == 2:
+        # the launch-point density is a libm pow (ocml here, glibc in the reference): n1 within an ulp or two
+        np.testing.assert_allclose(n0, g["rindex_vec0_full"], rtol=2e-15, atol=0)
+    else:
+        np.testing.assert_array_equal(n0, g["rindex_vec0_full"])
     tab = {k[4:]: (float(g[k]) if g[k].ndim == 0 else g[k]) for k in g.files if k.startswith("axi_")}
     _, _, w_host = initialize_ray_init(p, nml, tab or None)
     np.testing.assert_array_equal(w, w_host)
