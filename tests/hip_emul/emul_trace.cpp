@@ -12,8 +12,8 @@ RAYS_EMUL_DEFINE_GLOBALS
 #include "emul_dev_params.inc"
 #include "../../rays_amd/csrc/rays_fan_setup.inc"
 
-// Instantiated here: two species with nv = 7 | 8 for every equilibrium; for the slab also nv = 12 | 13
-// (integrate_eq_gradients) and three species (nv = 7).
+// Instantiated here: two species with nv = 7 | 8 for every equilibrium; nv = 12 (integrate_eq_gradients)
+// for the slab and Solovev; for the slab also nv = 13 and three species (nv = 7).
 template <int EQ, int DERIV, int NS, int NV>
 static int run1(int solver, const rays::DevParams& D, const rays::TraceArgs& A) {
   threadIdx.x = 0; blockIdx.x = 0; blockDim.x = 1; gridDim.x = 1;
@@ -25,8 +25,10 @@ template <int EQ, int DERIV>
 static int run(int solver, int ns, int nv, const rays::DevParams& D, const rays::TraceArgs& A) {
   if (ns == 2 && nv == 7) return run1<EQ, DERIV, 2, 7>(solver, D, A);
   if (ns == 2 && nv == 8) return run1<EQ, DERIV, 2, 8>(solver, D, A);
-  if constexpr ((EQ & 3) == 0) {
+  if constexpr ((EQ & 3) != 2) {
     if (ns == 2 && nv == 12) return run1<EQ, DERIV, 2, 12>(solver, D, A);
+  }
+  if constexpr ((EQ & 3) == 0) {
     if (ns == 2 && nv == 13) return run1<EQ, DERIV, 2, 13>(solver, D, A);
     if (ns == 3 && nv == 7) return run1<EQ, DERIV, 3, 7>(solver, D, A);
   }
