@@ -30,6 +30,9 @@ CASES = [
     ("gold_solovev64_sg_cold", "gold_solovev64_sg_cold.in", list(range(0, 64, 5)), 0, 0),
     ("gold_solovev64_sg_num", "gold_solovev64_sg_num.in", list(range(0, 64, 5)), 0, 0),
     ("gold_solovev64_rk4_num", "gold_solovev64_rk4_num.in", list(range(0, 64, 5)), 0, 0),
+    # the other root of the launcher's dispersion solve: wave_mode = 'slow' (Solovev, SG) and 'fast' (slab, RK4)
+    ("gold_solovev64_slow_sg", "gold_solovev64_slow_sg.in", list(range(0, 64, 7)), 0, 0),
+    ("gold_slab16_fast_rk4", "gold_slab16_fast_rk4.in", None, 0, 0),
     # ray_param = 'arcl' + integrate_eq_gradients: the nv = 12 SG kernel on the Solovev equilibrium
     ("gold_solovev64_arcl_grad_sg", "gold_solovev64_arcl_grad_sg.in", list(range(0, 64, 9)), 0, 0),
     # non-unit profile exponents: the general (libm pow) kernels

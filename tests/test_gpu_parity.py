@@ -16,9 +16,9 @@ RK4_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_num"
              "gold_solovev_evanescent_rk4",
              "gold_solovev64_damp_rk4", "gold_axisym64_eqdsk_damp_rk4",
              "gold_slab_toroid_parab_arcl_grad_rk4", "gold_slab_lin2_rk4_num",
-             "gold_axisym64_eqdsk_tspline_rk4_num"]
+             "gold_axisym64_eqdsk_tspline_rk4_num", "gold_slab16_fast_rk4"]
 SG_CASES = ["gold_solovev64_sg_cold", "gold_solovev64_sg_num", "gold_solovev64_damp_sg", "gold_axisym64_eqdsk_damp_sg",
-            "gold_solovev64_arcl_grad_sg",
+            "gold_solovev64_arcl_grad_sg", "gold_solovev64_slow_sg",
             "gold_slab_shear_gauss_3spec_sg_num"]
 # Gaussian density (libm exp in the profile) differentiated numerically: deriv_num's differences of D
 # over 1e-6 offsets amplify an ulp of exp (ocml here, glibc in the reference) by ~1e8 at every RHS,
