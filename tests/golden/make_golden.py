@@ -33,6 +33,9 @@ CASES = [
     # the other root of the launcher's dispersion solve: wave_mode = 'slow' (Solovev, SG) and 'fast' (slab, RK4)
     ("gold_solovev64_slow_sg", "gold_solovev64_slow_sg.in", list(range(0, 64, 7)), 0, 0),
     ("gold_slab16_fast_rk4", "gold_slab16_fast_rk4.in", None, 0, 0),
+    # stop flags the other fixtures do not reach: 'y out_of_bounds', 'z out_of_bounds', 'negative_temp'
+    ("gold_slab_box_exits_rk4", "gold_slab_box_exits_rk4.in", None, 0, 0),
+    ("gold_slab_negative_temp_rk4", "gold_slab_negative_temp_rk4.in", None, 0, 0),
     # ray_param = 'arcl' + integrate_eq_gradients: the nv = 12 SG kernel on the Solovev equilibrium
     ("gold_solovev64_arcl_grad_sg", "gold_solovev64_arcl_grad_sg.in", list(range(0, 64, 9)), 0, 0),
     # non-unit profile exponents: the general (libm pow) kernels
