@@ -33,9 +33,10 @@ CASES = [
     # the other root of the launcher's dispersion solve: wave_mode = 'slow' (Solovev, SG) and 'fast' (slab, RK4)
     ("gold_solovev64_slow_sg", "gold_solovev64_slow_sg.in", list(range(0, 64, 7)), 0, 0),
     ("gold_slab16_fast_rk4", "gold_slab16_fast_rk4.in", None, 0, 0),
-    # stop flags the other fixtures do not reach: 'y out_of_bounds', 'z out_of_bounds', 'negative_temp'
+    # stop flags the other fixtures do not reach: 'y out_of_bounds', 'z out_of_bounds', 'negative_temp', 'negative_dens'
     ("gold_slab_box_exits_rk4", "gold_slab_box_exits_rk4.in", None, 0, 0),
     ("gold_slab_negative_temp_rk4", "gold_slab_negative_temp_rk4.in", None, 0, 0),
+    ("gold_slab_negative_dens_rk4", "gold_slab_negative_dens_rk4.in", None, 0, 0),
     # ray_param = 'arcl' + integrate_eq_gradients: the nv = 12 SG kernel on the Solovev equilibrium
     ("gold_solovev64_arcl_grad_sg", "gold_solovev64_arcl_grad_sg.in", list(range(0, 64, 9)), 0, 0),
     # non-unit profile exponents: the general (libm pow) kernels
@@ -51,6 +52,8 @@ CASES = [
     ("gold_axisym64_eqdsk_damp_rk4", "gold_axisym64_eqdsk_damp_rk4.in", list(range(0, 64, 5)), 10, 120),
     # the same with the Shampine-Gordon integrator: BASELINE config 5's kernel
     ("gold_axisym64_eqdsk_damp_sg", "gold_axisym64_eqdsk_damp_sg.in", list(range(0, 64, 5)), 0, 0),
+    # steep poloidal launch: every ray ends on 'out_of_plasma'
+    ("gold_axisym16_eqdsk_zexit_rk4", "gold_axisym16_eqdsk_zexit_rk4.in", None, 0, 0),
     # parabolic density with non-unit exponents (pow), splined Te and Ti, finite-difference dD
     ("gold_axisym64_eqdsk_tspline_rk4_num", "gold_axisym64_eqdsk_tspline_rk4_num.in", list(range(0, 64, 5)), 10, 60),
     # the slab models cfg 1 does not touch: toroid By/Bz + parabolic n (libm pow) and Te, ray_param = 'arcl',
