@@ -35,7 +35,9 @@ def _run(binary, cfg, d):
                     reason="reference binaries not built (oracle/build_ref.sh needs /root/reference)")
 @pytest.mark.parametrize("cfg", ["cfg1_slab16_rk4.in", "cfg2_solovev1024_rk4.in",
                                  "gold_solovev64_sg_cold.in", "gold_solovev64_rk4_num.in",
-                                 "gold_solovev64_damp_rk4.in", "gold_axisym64_eqdsk_damp_rk4.in"])
+                                 "gold_solovev64_damp_rk4.in", "gold_axisym64_eqdsk_damp_rk4.in",
+                                 "gold_slab_lin2_rk4_num.in", "gold_slab_negative_dens_rk4.in",
+                                 "gold_solovev64_slow_sg.in"])
 def test_fortran_dropin_equals_reference_binary(cfg):
     with tempfile.TemporaryDirectory() as d:
         ref = _run(REF, cfg, os.path.join(d, "ref"))
