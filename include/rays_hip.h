@@ -300,16 +300,18 @@ int rays_hip_ray_init_device(const rays_params_t* p, const rays_fan_t* fan, int 
  * Replaces calculate_deposition_profiles / bin_a_ray (post_process_lib/deposition_profiles_m.f90:
  * 228-292) with its evaluators Ptotal_axisym_psi / Ptotal_axisym_rho (:458-503) and the uniform
  * grid binner (math_functions_lib/bin_to_uniform_grid_m.f90: binner_real), for
- * equilib_model = 'axisym_toroid' runs with damping (nv >= 8), applied to the trajectory arrays
- * where rays_hip_trace_device left them.
+ * equilib_model = 'axisym_toroid' runs with damping (nv >= 8), and the slab's Ptotal_x (evaluator
+ * Ptotal_x_slab_evaluator :438-452, grid [xmin, xmax] of the slab box :134-137), applied to the
+ * trajectory arrays where rays_hip_trace_device left them.
  *   d_work[n_bins][nray]   per-ray binned power: the reference's work(n_bins, nray), stored bin-major
  *                          (scratch of the call; transposed so that the reduction reads coalesce)
  *   d_profile_out[n_bins]  = d_profile_in (or 0) + sum over rays IN RAY ORDER, the order of the
  *                          reference's sum(work, 2): ranks that hold consecutive ray blocks chain
  *                          their partial sums through d_profile_in and obtain the single-process
  *                          result bit for bit (a few-KB exchange instead of the trajectory gather).
- * Grid = [0, 1] in psiN or rho; the reference's default is n_bins = 100 (n_bins <= 320 here). */
-enum { RAYS_DEP_PTOTAL_PSI = 0, RAYS_DEP_PTOTAL_RHO = 1 };
+ * Grid = [0, 1] in psiN or rho, [xmin, xmax] for Ptotal_x; the reference's default is n_bins = 100
+ * (n_bins <= 320 here). */
+enum { RAYS_DEP_PTOTAL_PSI = 0, RAYS_DEP_PTOTAL_RHO = 1, RAYS_DEP_PTOTAL_X = 2 };
 /* rho(psiN) spline of the eqdsk equilibrium (rho_profile of eqdsk_magnetics_spline_interp_m.f90:42,
  * 190-193; fspl(4, n) on grid(n)); needed for RAYS_DEP_PTOTAL_RHO.  Copied. */
 int rays_hip_set_rho_table(const double* grid, const double* fspl, int n);

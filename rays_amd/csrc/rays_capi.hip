@@ -812,22 +812,26 @@ int rays_hip_deposition_device(const rays_params_t* p, int which, int n_bins, in
                                const double* d_profile_in, double* d_profile_out, void* hip_stream) {
   int rc = rays_hip_check_params(p);
   if (rc) return rc;
-  if (p->equilib_model != RAYS_EQ_AXISYM)  // deposition_profiles_m.f90:141-222 knows slab and axisym_toroid
-    return fail("rays_hip_deposition: only equilib_model = 'axisym_toroid' profiles are on the device path");
+  if (p->equilib_model != RAYS_EQ_AXISYM && p->equilib_model != RAYS_EQ_SLAB)  // deposition_profiles_m.f90:129-222
+    return fail("initialize_deposition_profiles: unimplemented equilib_model");
   if (p->nv < 8 || p->damping_model == RAYS_DAMP_NONE)
     return fail("rays_hip_deposition: needs a run with damping (ray_vec(8) = absorbed power fraction)");
-  if (which != RAYS_DEP_PTOTAL_PSI && which != RAYS_DEP_PTOTAL_RHO)
-    return fail("initialize_deposition_profiles: unimplemented axisym_toroid profile");  // :208-212
+  if (p->equilib_model == RAYS_EQ_SLAB ? which != RAYS_DEP_PTOTAL_X
+                                       : (which != RAYS_DEP_PTOTAL_PSI && which != RAYS_DEP_PTOTAL_RHO))
+    return fail("initialize_deposition_profiles: unimplemented profile for this equilib_model");  // :162-169, 204-212
   if (n_bins < 1 || nray < 0) return fail("rays_hip_deposition: bad n_bins / nray");
   if (!d_ray_vec || !d_npoints || !d_initial_ray_power || !d_work || !d_profile_out)
     return fail("rays_hip_deposition: null device pointer");
   rays::DevParams D = make_dev_params(*p);
-  rc = get_axisym_device(&D);
-  if (rc) return rc;
+  if (p->equilib_model == RAYS_EQ_AXISYM) {
+    rc = get_axisym_device(&D);
+    if (rc) return rc;
+  }
   rays::DepArgs A;
   A.which = which;
   A.n_bins = n_bins; A.nray = nray; A.nv = p->nv; A.npt = p->nstep_max + 1;
-  A.grid_min = 0.0; A.grid_max = 1.0;  // :180-181
+  A.grid_min = 0.0; A.grid_max = 1.0;  // :176-177
+  if (which == RAYS_DEP_PTOTAL_X) { A.grid_min = p->slab.xmin; A.grid_max = p->slab.xmax; }  // :136-137
   A.ray_vec = d_ray_vec; A.npoints = d_npoints; A.power = d_initial_ray_power; A.work = d_work;
   A.rho_grid = nullptr; A.rho_fspl = nullptr; A.n_rho = 0;
   if (which == RAYS_DEP_PTOTAL_RHO) {

@@ -20,7 +20,7 @@
 namespace rays {
 
 struct DepArgs {
-  int which;  // RAYS_DEP_PTOTAL_PSI | RAYS_DEP_PTOTAL_RHO
+  int which;  // RAYS_DEP_PTOTAL_PSI | RAYS_DEP_PTOTAL_RHO | RAYS_DEP_PTOTAL_X
   int n_bins, nray, nv, npt;
   double grid_min, grid_max;
   const double* ray_vec;   // [nray][npt][nv]
@@ -32,9 +32,10 @@ struct DepArgs {
   double* work;            // [n_bins][nray]
 };
 
-// grid value of a ray point: psiN or rho(psiN) at (x, y, z)
+// grid value of a ray point: psiN or rho(psiN) at (x, y, z); x itself for the slab's Ptotal_x
 RAYS_DEV double dep_grid_value(const DevParams& P, const DepArgs& D, const double* v) {
   const double x = v[0], y = v[1], z = v[2];
+  if (D.which == 2) return x;  // Ptotal_x_slab_evaluator (deposition_profiles_m.f90:449)
   const double r = sqrt(x * x + y * y);
   double f6[6];
   spl2_fpp(P, r, z, f6);

@@ -174,7 +174,7 @@ def ray_init_device(p: RaysParams, fan: RaysFan, nray_max: int, d_rvec0: int, d_
     return nray.value
 
 
-DEP_PROFILES = {"Ptotal_psi": 0, "Ptotal_rho": 1}
+DEP_PROFILES = {"Ptotal_psi": 0, "Ptotal_rho": 1, "Ptotal_x": 2}
 
 
 def set_rho_table(grid, fspl):

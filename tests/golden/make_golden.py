@@ -33,6 +33,8 @@ CASES = [
     # the other root of the launcher's dispersion solve: wave_mode = 'slow' (Solovev, SG) and 'fast' (slab, RK4)
     ("gold_solovev64_slow_sg", "gold_solovev64_slow_sg.in", list(range(0, 64, 7)), 0, 0),
     ("gold_slab16_fast_rk4", "gold_slab16_fast_rk4.in", None, 0, 0),
+    # slab with a fundamental ECH resonance layer: damping on the slab + the 'Ptotal_x' deposition profile
+    ("gold_slab16_damp_rk4", "gold_slab16_damp_rk4.in", None, 0, 0),
     # stop flags the other fixtures do not reach: 'y out_of_bounds', 'z out_of_bounds', 'negative_temp', 'negative_dens'
     ("gold_slab_box_exits_rk4", "gold_slab_box_exits_rk4.in", None, 0, 0),
     ("gold_slab_negative_temp_rk4", "gold_slab_negative_temp_rk4.in", None, 0, 0),

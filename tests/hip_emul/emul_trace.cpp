@@ -132,14 +132,17 @@ extern "C" int rays_emul_ray_init(const rays_params_t* p, const rays_fan_t* fan,
 extern "C" int rays_emul_deposition(const rays_params_t* p, int which, int n_bins, int nray, const double* ray_vec,
                                     const int32_t* npoints, const double* power, const double* rho_grid,
                                     const double* rho_fspl, int n_rho, double* work, double* profile) {
-  if (p->equilib_model != RAYS_EQ_AXISYM || g_axi[2].empty()) return 3;
   rays::DevParams D = make_dev_params(*p);
-  D.a_nr = g_axi_n[0]; D.a_nz = g_axi_n[1]; D.a_n_rb = g_axi_n[2];
-  D.a_r_grid = g_axi[0].data(); D.a_z_grid = g_axi[1].data(); D.a_psi_fspl = g_axi[2].data();
-  D.a_rb_grid = g_axi[3].data(); D.a_rb_fspl = g_axi[4].data();
+  if (which != 2) {
+    if (p->equilib_model != RAYS_EQ_AXISYM || g_axi[2].empty()) return 3;
+    D.a_nr = g_axi_n[0]; D.a_nz = g_axi_n[1]; D.a_n_rb = g_axi_n[2];
+    D.a_r_grid = g_axi[0].data(); D.a_z_grid = g_axi[1].data(); D.a_psi_fspl = g_axi[2].data();
+    D.a_rb_grid = g_axi[3].data(); D.a_rb_fspl = g_axi[4].data();
+  }
   rays::DepArgs A;
   A.which = which; A.n_bins = n_bins; A.nray = nray; A.nv = p->nv; A.npt = p->nstep_max + 1;
   A.grid_min = 0.; A.grid_max = 1.;
+  if (which == 2) { A.grid_min = p->slab.xmin; A.grid_max = p->slab.xmax; }
   A.ray_vec = ray_vec; A.npoints = npoints; A.power = power; A.work = work;
   A.rho_grid = rho_grid; A.rho_fspl = rho_fspl; A.n_rho = n_rho;
   for (int r = 0; r < nray; r++) rays::deposit_ray(D, A, r, work + (size_t)r * n_bins, 1);

@@ -103,3 +103,20 @@ def test_deposition_source_on_host_equals_reference():
         for x in prof:
             q = q + x
         assert q == g["dep_q_sum"][which]
+
+
+def test_slab_deposition_source_on_host_equals_reference():
+    """'Ptotal_x' of a slab run with damping (Ptotal_x_slab_evaluator, deposition_profiles_m.f90:438-452;
+    grid = the slab box in x): work, profile and Q_sum bit for bit."""
+    from tests.common import padded_full_trajectories
+    g, nml, p = load_golden("gold_slab16_damp_rk4")
+    assert [str(n) for n in g["dep_names"]] == ["Ptotal_x"]
+    rv = padded_full_trajectories(g, p)
+    z = np.zeros(1)
+    work, prof = emul_lib.deposition(p, 2, int(g["dep_n_bins"]), rv, g["npoints_full"], g["dep_power"], z, np.zeros(4))
+    np.testing.assert_array_equal(work, g["dep_work"][0])
+    np.testing.assert_array_equal(prof, g["dep_profile"][0])
+    q = 0.0
+    for x in prof:
+        q = q + x
+    assert q == g["dep_q_sum"][0] and q > 0.05   # 16 rays x 0.99 absorbed x weight 1/256 (App. A-11)

@@ -18,7 +18,7 @@ RK4_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_num"
              "gold_slab_toroid_parab_arcl_grad_rk4", "gold_slab_lin2_rk4_num",
              "gold_axisym64_eqdsk_tspline_rk4_num", "gold_slab16_fast_rk4",
              "gold_slab_box_exits_rk4", "gold_slab_negative_temp_rk4", "gold_axisym16_eqdsk_zexit_rk4",
-             "gold_slab_negative_dens_rk4"]
+             "gold_slab_negative_dens_rk4", "gold_slab16_damp_rk4"]
 SG_CASES = ["gold_solovev64_sg_cold", "gold_solovev64_sg_num", "gold_solovev64_damp_sg", "gold_axisym64_eqdsk_damp_sg",
             "gold_solovev64_arcl_grad_sg", "gold_solovev64_slow_sg",
             "gold_slab_shear_gauss_3spec_sg_num"]
@@ -192,6 +192,34 @@ def test_device_deposition_profiles_match_reference():
                               power[h:].data_ptr(), w2.data_ptr(), part.data_ptr(), tot.data_ptr())
         torch.cuda.synchronize()
         np.testing.assert_array_equal(tot.cpu().numpy(), g["dep_profile"][which])
+
+
+def test_device_slab_deposition_profile_matches_reference():
+    """'Ptotal_x' (slab run with damping): work, profile and Q_sum of the reference post-processor bit for
+    bit from the trajectories of a device trace; an axisym profile name is refused for a slab run."""
+    import torch
+    from rays_amd.trace import DeviceTrace
+    g, nml, p = load_golden("gold_slab16_damp_rk4")
+    tr = DeviceTrace(p, g["rvec0_full"], g["rindex_vec0_full"])
+    tr.launch()
+    torch.cuda.synchronize()
+    nray, nb = tr.nray, int(g["dep_n_bins"])
+    np.testing.assert_array_equal(tr.npoints.cpu().numpy(), g["npoints_full"])
+    power = torch.as_tensor(g["dep_power"], device="cuda")
+    work = torch.zeros((nb, nray), dtype=torch.float64, device="cuda")
+    prof = torch.zeros(nb, dtype=torch.float64, device="cuda")
+    hip.deposition_device(p, "Ptotal_x", nb, nray, tr.ray_vec.data_ptr(), tr.npoints.data_ptr(), power.data_ptr(),
+                          work.data_ptr(), None, prof.data_ptr())
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(work.cpu().numpy().T, g["dep_work"][0])
+    np.testing.assert_array_equal(prof.cpu().numpy(), g["dep_profile"][0])
+    q = 0.0
+    for x in prof.cpu().numpy():
+        q = q + x
+    assert q == g["dep_q_sum"][0]
+    with pytest.raises(hip.RaysHipError):
+        hip.deposition_device(p, "Ptotal_psi", nb, nray, tr.ray_vec.data_ptr(), tr.npoints.data_ptr(), power.data_ptr(),
+                              work.data_ptr(), None, prof.data_ptr())
 
 
 def test_device_ray_init_all_evanescent_and_missing_rho_table():
