@@ -149,9 +149,12 @@ def test_ray_launcher_and_deposition_config_errors_need_no_gpu():
     slab.model = 2                                         # simple_slab launcher on a Solovev equilibrium
     with pytest.raises(hip.RaysHipError, match="slab"):
         hip.ray_init_host(p, slab, nray_max)
-    # deposition: needs axisym_toroid + damping
-    with pytest.raises(hip.RaysHipError, match="axisym_toroid"):
+    # deposition: the post-processor knows slab and axisym_toroid runs (deposition_profiles_m.f90:129-222) with damping
+    with pytest.raises(hip.RaysHipError, match="unimplemented equilib_model"):
         hip.deposition_device(p, "Ptotal_psi", 100, 1, 1, 1, 1, 1, None, 1)
+    gs, nmls, ps = load_golden("gold_slab16_damp_rk4")
+    with pytest.raises(hip.RaysHipError, match="unimplemented profile"):
+        hip.deposition_device(ps, "Ptotal_rho", 100, 1, 1, 1, 1, 1, None, 1)
     ga, nmla, pa = load_golden("gold_axisym64_eqdsk_damp_rk4")
     q = copy_params(pa)
     q.nv, q.damping_model = 7, 0
