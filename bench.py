@@ -233,7 +233,7 @@ def main():
         prof = torch.zeros(n_bins, dtype=torch.float64, device=dev)
 
         def accumulate(carry, out):
-            hip.deposition_device(p, "Ptotal_psi", n_bins, hi - lo, tr.ray_vec.data_ptr(), tr.npoints.data_ptr(),
+            hip.deposition_device(p, "Ptotal_x" if p.equilib_model == 0 else "Ptotal_psi", n_bins, hi - lo, tr.ray_vec.data_ptr(), tr.npoints.data_ptr(),
                                   power.data_ptr(), work.data_ptr(), None if carry is None else carry.data_ptr(),
                                   out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
 
