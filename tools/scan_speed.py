@@ -1,5 +1,6 @@
 """Fused ray_scan vs the reference's serial loop over runs, on the 1024-ray Solovev fan."""
 import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # rays_amd/scan.py: HW_QUEUES_ENV, before HIP starts
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
