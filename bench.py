@@ -12,6 +12,9 @@ in initialize_ray_results_m (ray_results_m.f90:154-164), not inside trace_rays.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config configs/....in]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment) starts its N ranks
+itself -- child processes, spawned before the parent touches a GPU -- and relays rank 0's line.
+
 N > 1 is weak scaling: the fan grows to 256*N x 256 rays over the same launch-angle range and is
 block-partitioned, 65536 contiguous rays per rank (the reference's `schedule(static)`).
 """
@@ -33,6 +36,65 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: vector FP64 (every instruction an FMA)
+N_SIMD = 256 * 4         # 256 CUs x 4 SIMDs
+FP64_CLK_PER_WAVE_INST = 4  # a wave64 FP64 VALU instruction occupies its SIMD's 16 lanes for 4 clocks
+
+
+def self_launch(args):
+    """`--gpus N` with no launcher: start the N ranks as child processes (the parent has not touched a GPU
+    and never will), relay rank 0's stdout, exit with the worst return code."""
+    import socket
+
+    import torch
+
+    ndev = torch.cuda.device_count()   # counting devices does not initialise the GPU
+    if ndev < args.gpus and not os.environ.get("RAYS_BENCH_SHARE_GPU"):
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible "
+                         "(RAYS_BENCH_SHARE_GPU=1 rehearses N ranks on fewer GPUs)")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [pr.wait() for pr in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    raise SystemExit(max(abs(rc) for rc in rcs))
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def metric_name(p, rays_per_gpu):
+    eq = {0: "slab", 1: "Solovev", 2: "eqdsk"}.get(int(p.equilib_model), "?")
+    n = f"{rays_per_gpu // 1024}k" if rays_per_gpu % 1024 == 0 else str(rays_per_gpu)
+    return f"ray-steps/sec (whole node), {n}-ray {eq} fan"
+
+
+def simd_idle_fraction(npoints, resident_lanes=N_SIMD * 64):
+    """Share of SIMD-time without a wave, from the recorded step counts, when the fan fits the resident lanes
+    (one wave per SIMD, nothing to refill): wave w holds rays 64w..64w+63 and lives as long as its longest ray."""
+    n = len(npoints)
+    if n == 0 or n > resident_lanes:
+        return None
+    steps = np.maximum(npoints.astype(np.int64) - 1, 0)
+    pad = (-n) % 64
+    per_wave = np.pad(steps, (0, pad)).reshape(-1, 64).max(axis=1)
+    longest = per_wave.max()
+    return None if longest == 0 else float(1.0 - per_wave.sum() / (N_SIMD * longest))
 
 
 def build_fan(cfg_path, world, fan_scale=1, nstep_max=None):
@@ -91,13 +153,27 @@ def cpu_baseline(cfg_path, budget_s=20.0):
             txt = re.sub(key_d + r"\s*=\s*[-\d.eE+]+", f"{key_d} = {d * sub!r}", txt)
             return txt
 
-        if "solovev_ray_init_nphi_ktheta_list" in nml:
+        if "n_rindex_theta" in text0:
             txt = scale(scale(text0, "n_rindex_theta", "delta_rindex_theta"), "n_rindex_phi", "delta_rindex_phi")
-            what = "the whole fan" if sub == 1 else f"same Solovev fan subsampled {sub}x{sub} in launch angle"
+            what = "the whole fan" if sub == 1 else f"same fan subsampled {sub}x{sub} in launch angle"
         else:
             txt = scale(scale(text0, "n_ky_launch", "delta_rindex_y0"), "n_kz_launch", "delta_rindex_z0")
             what = "the whole fan" if sub == 1 else f"same slab fan subsampled {sub}x{sub} in launch index"
         return txt, what + ", all steps"
+
+    def run_ref(text, threads=None):
+        """one run of the reference binary; threads: /openmp_list/ num_threads (None = all)"""
+        if threads is not None:
+            text = re.sub(r"&openmp_list.*?/", "", text, flags=re.S | re.I) + f"\n &openmp_list\n num_threads = {threads}\n/\n"
+        with tempfile.TemporaryDirectory() as d:
+            open(os.path.join(d, "rays.in"), "w").write(text)
+            for f in os.listdir(os.path.join(ROOT, "configs")):
+                if f.endswith(".geqdsk"):
+                    shutil.copy(os.path.join(ROOT, "configs", f), d)
+            env = dict(os.environ, RAYS_DUMP_FILE="none")
+            out = subprocess.run([ref], cwd=d, env=env, capture_output=True, text=True, timeout=600).stdout
+        return dict(l.split("=")[0].split()[-1:] + [l.split("=")[1].strip()]
+                    for l in out.splitlines() if l.startswith("RAYS_REF"))
 
     # the sample grows (4x4 -> 2x2 -> whole fan) while the next size is predicted to fit the budget
     text, sample = subsample(4)
@@ -105,25 +181,27 @@ def cpu_baseline(cfg_path, budget_s=20.0):
         best = None
         for sub in (4, 2, 1):
             text, sample = subsample(sub)
-            with tempfile.TemporaryDirectory() as d:
-                open(os.path.join(d, "rays.in"), "w").write(text)
-                env = dict(os.environ, RAYS_DUMP_FILE="none")
-                try:
-                    out = subprocess.run([ref], cwd=d, env=env, capture_output=True, text=True,
-                                         timeout=600).stdout
-                    vals = dict(l.split("=")[0].split()[-1:] + [l.split("=")[1].strip()]
-                                for l in out.splitlines() if l.startswith("RAYS_REF"))
-                    wall = float(vals["trace_wall_s"])
-                    best = dict(value=float(vals["steps_per_s"]), unit="ray-steps/s",
-                                cores=int(vals["threads"]), kind="reference",
-                                sample=sample + f" ({vals['nray']} rays); {vals['total_steps']} steps in {wall:.2f} s, "
-                                "reference RAYS_project trace_rays (amdflang -O2 -fopenmp), OpenMP over rays")
-                except Exception as e:  # keep what we have, or fall through to the port
-                    print(f"[bench] reference CPU baseline failed: {e}", file=sys.stderr)
-                    break
+            try:
+                vals = run_ref(text)
+                wall = float(vals["trace_wall_s"])
+                best = dict(value=float(vals["steps_per_s"]), unit="ray-steps/s",
+                            cores=int(vals["threads"]), kind="reference", cpu_model=cpu_model(),
+                            sample=sample + f" ({vals['nray']} rays); {vals['total_steps']} steps in {wall:.2f} s, "
+                            "reference RAYS_project trace_rays (amdflang -O2 -fopenmp), OpenMP over rays")
+            except Exception as e:  # keep what we have, or fall through to the port
+                print(f"[bench] reference CPU baseline failed: {e}", file=sys.stderr)
+                break
             if 4.0 * wall > budget_s:
                 break
         if best is not None:
+            try:  # one thread: a 16x16-subsampled fan (256 rays), a few seconds
+                t1, s1 = subsample(16)
+                v1 = run_ref(t1, threads=1)
+                best["threads1"] = dict(value=float(v1["steps_per_s"]), unit="ray-steps/s", cores=1,
+                                        sample=s1 + f" ({v1['nray']} rays); {v1['total_steps']} steps in "
+                                        f"{float(v1['trace_wall_s']):.2f} s")
+            except Exception as e:
+                print(f"[bench] one-thread CPU baseline failed: {e}", file=sys.stderr)
             return best
         text, sample = subsample(4)
     from tests import oracle_lib
@@ -138,7 +216,7 @@ def cpu_baseline(cfg_path, budget_s=20.0):
     o = oracle_lib.trace(p, r0, n0, nthreads=cores)
     dt = time.perf_counter() - t0
     steps = int(np.maximum(o["npoints"].astype(np.int64) - 1, 0).sum())
-    return dict(value=steps / dt, unit="ray-steps/s", cores=cores, kind="port",
+    return dict(value=steps / dt, unit="ray-steps/s", cores=cores, kind="port", cpu_model=cpu_model(),
                 sample=sample + f"; {steps} steps in {dt:.2f} s, C restatement (oracle/), OpenMP over rays")
 
 
@@ -163,6 +241,10 @@ def main():
                     help="diagnostic: rays per GPU = 65536 x this (finer n_theta); not the headline config")
     ap.add_argument("--nstep-max", type=int, default=None, help="diagnostic: override nstep_max")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)   # does not return
 
     import torch
     import torch.distributed as dist
@@ -173,8 +255,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly --gpus ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     ndev = torch.cuda.device_count()
@@ -245,15 +327,15 @@ def main():
             else:
                 chain.reduce_unordered(accumulate)  # per-rank ordered sums + one RCCL reduce
 
-    def step(ev=None):
+    def step(ev=None, with_exchange=True):
         if ev is not None:
             ev[0].record()
         tr.launch(zero_fill=False)
         if ev is not None:
             ev[1].record()
-        if gather is not None:
+        if with_exchange and gather is not None:
             gather()
-        if deposit is not None:
+        if with_exchange and deposit is not None:
             deposit()
 
     def barrier():
@@ -263,25 +345,56 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n, **kw):
+        """n steps between two barrier + synchronize brackets; MAX over ranks of the wall time"""
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(n):
+            step(events[k], **kw)
+        barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item()), float(np.mean([a.elapsed_time(b) for a, b in events]))
+
     for _ in range(args.warmup):
         step()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events[k])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    # ---- THE timed region of the contract: exactly K steps (trace + this pass's exchange) -------------------
+    elapsed, kernel_ms = timed(args.steps)
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    # ---- diagnosis of an N > 1 line: where does the time go? (outside the timed region above) ---------------
+    ones = torch.ones(1, dtype=torch.int64, device=dev)
     tot = torch.tensor([steps_local], dtype=torch.int64, device=dev)
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)   # RCCL: how many ranks really took part
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    elapsed = float(tmax.item())
+    n_ranks_seen = int(ones.item())
     total_steps = int(tot.item())
+    split = {}
+    if world > 1 and gather is not None:
+        el_trace, _ = timed(args.steps, with_exchange=False)        # the same K passes without the exchange
+        reps = 3
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):                                       # exchange alone: pack + RCCL send/recv + unpack,
+            tg.gather(tr.ray_vec, tr.residual, tr.npoints, tr.stop_code)   # completed before the next starts
+            torch.cuda.synchronize()
+        barrier()
+        g = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
+        dist.all_reduce(g, op=dist.ReduceOp.MAX)
+        gather_s = float(g.item())
+        pts = torch.tensor([points_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(pts, op=dist.ReduceOp.MAX)
+        peer_bytes = 8.0 * (nv + 1) * int(pts.item()) + 8.0 * (hi - lo)   # packed points + npoints/stop codes
+        split = dict(value_trace_only=total_steps / (el_trace / args.steps),
+                     trace_only_ms_per_step=1e3 * el_trace / args.steps,
+                     gather_ms=1e3 * gather_s, gather_bytes_per_peer=peer_bytes,
+                     gather_GBps_per_peer=peer_bytes / gather_s / 1e9,
+                     gather_GBps_into_root=peer_bytes * (world - 1) / gather_s / 1e9,
+                     gather_note="value = trace + gather as the metric is defined (the exchange of pass i runs behind the "
+                          "trace of pass i+1, so ms_per_step ~ max(trace, gather)); value_trace_only = the same K "
+                          "passes with the exchange switched off; gather_ms = one exchange on its own")
 
     # the timed passes must have reproduced the first pass (deterministic kernels)
     assert int(torch.clamp(tr.npoints.to(torch.int64) - 1, min=0).sum().item()) == steps_local
@@ -300,18 +413,34 @@ def main():
         value = total_steps / (elapsed / args.steps)
         bytes_per_launch = 8.0 * (nv + 1) * steps_local  # 8*(nv+1) B per recorded step
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        # counters of the same command collected by tools/profile_bench.sh (rocprofv3 --pmc, separate passes):
+        # profiles/counters.json = {config file name: {hbm_bytes_per_launch, fp64_wave_insts: {...}, ...}}
+        traffic, fp64 = None, None
+        cpath = os.path.join(ROOT, "profiles", "counters.json")
+        if os.path.exists(cpath) and args.fan_scale == 1 and args.nstep_max is None:
             try:
-                t = json.load(open(tpath))
-                if t.get("config") == os.path.basename(args.config):
-                    traffic = t.get("hbm_bytes_per_launch")
-            except Exception:
-                pass
+                c = json.load(open(cpath)).get(os.path.basename(args.config))
+                if c and c.get("kernel") == hip.kernel_name(p, hi - lo):
+                    traffic = c.get("hbm_bytes_per_launch")
+                    w = c.get("fp64_wave_insts")
+                    if w:
+                        insts = sum(w.values())
+                        flop = 64.0 * (w.get("add", 0) + w.get("mul", 0) + w.get("trans", 0)) + 128.0 * w.get("fma", 0)
+                        clk = c.get("effective_clock_GHz") or 2.4
+                        fp64 = {"fp64_wave_insts": insts, "by_kind": w,
+                                "issue_frac": insts * FP64_CLK_PER_WAVE_INST / (N_SIMD * kernel_ms * 1e-3 * clk * 1e9),
+                                "tflops": flop / (kernel_ms * 1e-3) / 1e12, "peak_tflops": FP64_PEAK_TFLOPS,
+                                "frac": flop / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                                "valu_insts": c.get("valu_insts"), "clock_GHz": clk, "source": c.get("source"),
+                                "note": "issue_frac = FP64 wave-instructions x 4 clk / (1024 SIMDs x kernel time x clock): "
+                                        "the share of all FP64 issue slots used; tflops counts add/mul/trans as 1 flop "
+                                        "and fma as 2 per lane (FMA contraction is off for bit-parity with the reference)"}
+            except Exception as e:
+                print(f"[bench] profiles/counters.json unreadable: {e}", file=sys.stderr)
+        idle = simd_idle_fraction(tr.npoints.cpu().numpy()) if world == 1 else None
         line = {
-            "metric": "ray-steps/sec (whole node), 64k-ray Solovev fan",
-            "value": value, "unit": "ray-steps/s", "n_gpus": world, "steps": args.steps,
+            "metric": metric_name(p, hi - lo),
+            "value": value, "unit": "ray-steps/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": os.path.basename(args.config),
@@ -329,8 +458,14 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "bound by instruction issue of one wave per SIMD (~3.6k instructions per 64-B step), not by HBM: DESIGN.md 4.5"},
+                         "note": "the contract's HBM figure; the path is bound by FP64 instruction issue "
+                                 "(roofline_fp64), not by HBM: DESIGN.md 4.5"},
         }
+        if fp64 is not None:
+            line["roofline_fp64"] = fp64
+        if idle is not None:
+            line["simd_idle_frac"] = idle
+        line.update(split)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(line))

@@ -161,6 +161,11 @@ typedef struct rays_params {
 /* Select up to ngpu visible devices for rays_hip_trace (0 = all).  Returns the number in use,
  * or a negative value on failure.  Optional: rays_hip_trace initialises lazily. */
 int rays_hip_init(int ngpu);
+/* Explicit device list for rays_hip_trace: slot i of the ray partition runs on device_ids[i]
+ * (1 <= n <= 16).  A device may be listed more than once: its slots then run concurrently on that
+ * device, each with its own host thread, stream and staging buffers, so one slot's device-to-host
+ * copy overlaps another's trace.  Returns n, or a negative value on failure. */
+int rays_hip_init_devices(int n, const int* device_ids);
 int rays_hip_finalize(void);
 int rays_hip_device_count(void);
 /* sizeof(rays_params_t) as compiled into the library: lets a foreign-language binding (ctypes,
@@ -234,6 +239,30 @@ int rays_hip_trace_device(const rays_params_t* p, int nray,
                           double* d_ray_vec, double* d_residual, int32_t* d_npoints,
                           int32_t* d_stop_code, double* d_end_ray_vec, double* d_end_residuals,
                           double* d_max_residuals, void* hip_stream, int flags);
+
+/* ---- ray_scan fused into ONE launch ---------------------------------------
+ * Replaces the reference's serial scan loop (ray_scan/ray_scan.f90:33-49: update_scan_parameter +
+ * initialize + trace_rays per run; scanner_m.f90:174-205: scan_parameter = 'ds', the only physical one)
+ * by one launch over n_runs x nray rays: run r traces the fan rvec0/rindex_vec0[nray][3] with
+ * ds = d_ds_values[r]; everything else comes from p.  Outputs are the arrays of rays_hip_trace_device
+ * with a leading run dimension: ray_vec[n_runs][nray][nstep_max+1][nv], npoints[n_runs][nray], ...
+ * Each run's results are those of a stand-alone trace with that ds, bit for bit. */
+int rays_hip_scan_device(const rays_params_t* p, int n_runs, const double* d_ds_values, int nray,
+                         const double* d_rvec0, const double* d_rindex_vec0, double* d_ray_vec,
+                         double* d_residual, int32_t* d_npoints, int32_t* d_stop_code,
+                         double* d_end_ray_vec, double* d_end_residuals, double* d_max_residuals,
+                         void* hip_stream, int flags);
+
+/* ---- one output step from arbitrary states: the ode_m interface --------------------------------
+ * Batched image of `call ode_solver(eqn_ray, nv, v, s, sout, ray_stop)` (ode_m.f90:218-254, with
+ * sout = s + ds and, for SG_ODE, ray_stop%rel_err/abs_err at rel_err0/abs_err0 as after
+ * ray_init_ode_solver, ode_m.f90:182-214) followed by the check_save trace_rays applies to the new point
+ * (ray_tracing.f90:212-243).  d_v0[n][nv] states, d_s0[n] ray parameters (NULL = 0) -> d_v1[n][nv],
+ * d_resid[n] (may be NULL), d_stop_code[n] (RAYS_STOP_NONE when the step was taken and kept; then v1 is
+ * the new state; otherwise v1 = 0).  The states must satisfy the dispersion relation well enough to pass
+ * check_save at v0, as any recorded trajectory point does.  Synchronises hip_stream. */
+int rays_hip_ode_step_device(const rays_params_t* p, int n, const double* d_v0, const double* d_s0,
+                             double* d_v1, double* d_resid, int32_t* d_stop_code, void* hip_stream);
 
 /* Name of the kernel specialisation rays_hip_trace_device would launch for p (for profiling
  * scripts: matches the rocprofv3 kernel-trace name prefix). */

@@ -5,11 +5,13 @@
 // error message.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -119,9 +121,7 @@ const rays::KernelEntry* find_kernel(const rays_params_t& p, long long nray = 0)
   int ncu = 256;
   {
     int dev = 0;
-    hipDeviceProp_t prop;
-    if (nray > 0 && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      ncu = prop.multiProcessorCount;
+    if (nray > 0 && hipGetDevice(&dev) == hipSuccess) ncu = device_cu_count(dev);
   }
   bool big = nray >= 2ll * ncu * 256;  // >= two waves per SIMD
   if (const char* f = std::getenv("RAYS_HIP_FORCE_WAVES_PER_SIMD"))  // developer measurement: "1" | "2"
@@ -203,24 +203,48 @@ int get_axisym_device(rays::DevParams* D) {
   return 0;
 }
 
-// Per-device ring of refill counters (allocated once, outside any stream capture).
-struct DeviceWorkspace {
-  unsigned int* counters = nullptr;
-  int next = 0;
-};
+// Per-device ring of refill counters.  A slot is handed to one launch at a time: the launch records
+// the slot's event behind its kernel, and a later launch that comes round to the same slot waits for
+// that event first (more than kCounterSlots launches in flight on one device would otherwise share a
+// counter and silently skip rays).
 constexpr int kCounterSlots = 256;
 constexpr int kCounterStride = 32;  // 128 B apart
-std::vector<DeviceWorkspace> g_ws;
+struct DeviceWorkspace {
+  unsigned int* counters = nullptr;
+  hipEvent_t done[kCounterSlots] = {};
+  bool used[kCounterSlots] = {};
+  int next = 0;
+};
+DeviceWorkspace g_ws[16];
 
-int get_counter(unsigned int** out) {
+int get_counter(unsigned int** out, int* slot_out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return fail("rays_hip: device ordinal >= 16");
+  hipEvent_t wait_for = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceWorkspace& w = g_ws[dev];
+    if (!w.counters) HIP_TRY(hipMalloc(&w.counters, sizeof(unsigned int) * kCounterSlots * kCounterStride));
+    const int slot = w.next;
+    w.next = (w.next + 1) % kCounterSlots;
+    if (!w.done[slot]) HIP_TRY(hipEventCreateWithFlags(&w.done[slot], hipEventDisableTiming));
+    if (w.used[slot]) wait_for = w.done[slot];
+    w.used[slot] = true;
+    *out = w.counters + (size_t)slot * kCounterStride;
+    *slot_out = slot;
+  }
+  if (wait_for && hipEventQuery(wait_for) != hipSuccess) {
+    (void)hipGetLastError();
+    HIP_TRY(hipEventSynchronize(wait_for));  // the launch that last used this slot is still running
+  }
+  return 0;
+}
+int counter_launched(int slot, hipStream_t stream) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_mu);
-  if ((int)g_ws.size() <= dev) g_ws.resize(dev + 1);
-  DeviceWorkspace& w = g_ws[dev];
-  if (!w.counters) HIP_TRY(hipMalloc(&w.counters, sizeof(unsigned int) * kCounterSlots * kCounterStride));
-  *out = w.counters + (size_t)w.next * kCounterStride;
-  w.next = (w.next + 1) % kCounterSlots;
+  HIP_TRY(hipEventRecord(g_ws[dev].done[slot], stream));
   return 0;
 }
 
@@ -294,20 +318,48 @@ int rays_hip_init(int ngpu) {
     return -1;
   }
   if (ngpu <= 0 || ngpu > n) ngpu = n;
+  if (ngpu > 16) ngpu = 16;
   std::lock_guard<std::mutex> lk(g_mu);
   g_devices.clear();
   for (int i = 0; i < ngpu; i++) g_devices.push_back(i);
   return ngpu;
 }
 
+int rays_hip_init_devices(int n, const int* device_ids) {
+  const int visible = rays_hip_device_count();
+  if (visible <= 0) {
+    g_err = "rays_hip_init_devices: no HIP device visible";
+    return -1;
+  }
+  if (n <= 0 || n > 16 || !device_ids) {
+    g_err = "rays_hip_init_devices: 1..16 device slots";
+    return -1;
+  }
+  for (int i = 0; i < n; i++)
+    if (device_ids[i] < 0 || device_ids[i] >= visible) {
+      g_err = "rays_hip_init_devices: device ordinal out of range";
+      return -1;
+    }
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_devices.assign(device_ids, device_ids + n);
+  return n;
+}
+
 static void release_cached_device_blocks();
 int rays_hip_finalize(void) {
   std::lock_guard<std::mutex> lk(g_mu);
-  for (size_t d = 0; d < g_ws.size(); d++)
+  for (int d = 0; d < 16; d++)
     if (g_ws[d].counters) {
-      (void)hipSetDevice((int)d);
+      (void)hipSetDevice(d);
+      (void)hipDeviceSynchronize();
       (void)hipFree(g_ws[d].counters);
       g_ws[d].counters = nullptr;
+      for (int i = 0; i < kCounterSlots; i++) {
+        if (g_ws[d].done[i]) (void)hipEventDestroy(g_ws[d].done[i]);
+        g_ws[d].done[i] = nullptr;
+        g_ws[d].used[i] = false;
+      }
+      g_ws[d].next = 0;
     }
   release_cached_device_blocks();
   g_devices.clear();
@@ -373,25 +425,27 @@ const char* rays_hip_kernel_name_for(const rays_params_t* p, int nray) {
   return find_kernel(*p, nray)->name;
 }
 
-int rays_hip_trace_device(const rays_params_t* p, int nray, const double* d_rvec0,
-                          const double* d_rindex_vec0, double* d_ray_vec, double* d_residual,
-                          int32_t* d_npoints, int32_t* d_stop_code, double* d_end_ray_vec,
-                          double* d_end_residuals, double* d_max_residuals, void* hip_stream,
-                          int flags) {
-  int rc = rays_hip_check_params(p);
-  if (rc) return rc;
-  if (nray < 0) return fail("rays_hip_trace_device: nray < 0");
-  if (nray == 0) return 0;
-  if (!d_rvec0 || !d_rindex_vec0 || !d_ray_vec || !d_residual || !d_npoints || !d_stop_code)
-    return fail("rays_hip_trace_device: null device pointer");
-  hipStream_t stream = (hipStream_t)hip_stream;
+// Common launcher of the trace kernels: `extra` carries the optional per-ray starting conditions and the
+// per-run steps of a fused scan (rays_trace.hpp: TraceArgs).
+namespace {
+struct TraceExtras {
+  const double* v0 = nullptr;
+  const double* s0 = nullptr;
+  const double* ds_run = nullptr;
+  int rays_per_run = 0;
+};
+int launch_trace(const rays_params_t* p, int nray, const double* d_rvec0, const double* d_rindex_vec0,
+                 double* d_ray_vec, double* d_residual, int32_t* d_npoints, int32_t* d_stop_code,
+                 double* d_end_ray_vec, double* d_end_residuals, double* d_max_residuals, hipStream_t stream,
+                 int flags, const TraceExtras& extra) {
   const size_t npt = (size_t)p->nstep_max + 1;
   if (!(flags & RAYS_TRACE_NO_ZERO_FILL)) {  // ray_results_m.f90:154-164
     HIP_TRY(hipMemsetAsync(d_ray_vec, 0, sizeof(double) * npt * (size_t)p->nv * (size_t)nray, stream));
     HIP_TRY(hipMemsetAsync(d_residual, 0, sizeof(double) * npt * (size_t)nray, stream));
   }
   unsigned int* counter = nullptr;
-  rc = get_counter(&counter);
+  int counter_slot = 0;
+  int rc = get_counter(&counter, &counter_slot);
   if (rc) return rc;
   HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned int), stream));
   rays::TraceArgs A;
@@ -406,6 +460,10 @@ int rays_hip_trace_device(const rays_params_t* p, int nray, const double* d_rvec
   A.end_residuals = d_end_residuals;
   A.max_residuals = d_max_residuals;
   A.next_ray = counter;
+  A.v0 = extra.v0;
+  A.s0 = extra.s0;
+  A.ds_run = extra.ds_run;
+  A.rays_per_run = extra.rays_per_run;
   rays::DevParams D = make_dev_params(*p);
   if (p->damping_model == RAYS_DAMP_FUND_ECH) {
     const double* zf = nullptr;
@@ -430,15 +488,109 @@ int rays_hip_trace_device(const rays_params_t* p, int nray, const double* d_rvec
   int grid = 0;
   hipError_t e = find_kernel(*p, nray)->launch(D, A, stream, &grid);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
-  return 0;
+  return counter_launched(counter_slot, stream);
+}
+}  // namespace
+
+int rays_hip_trace_device(const rays_params_t* p, int nray, const double* d_rvec0,
+                          const double* d_rindex_vec0, double* d_ray_vec, double* d_residual,
+                          int32_t* d_npoints, int32_t* d_stop_code, double* d_end_ray_vec,
+                          double* d_end_residuals, double* d_max_residuals, void* hip_stream,
+                          int flags) {
+  int rc = rays_hip_check_params(p);
+  if (rc) return rc;
+  if (nray < 0) return fail("rays_hip_trace_device: nray < 0");
+  if (nray == 0) return 0;
+  if (!d_rvec0 || !d_rindex_vec0 || !d_ray_vec || !d_residual || !d_npoints || !d_stop_code)
+    return fail("rays_hip_trace_device: null device pointer");
+  return launch_trace(p, nray, d_rvec0, d_rindex_vec0, d_ray_vec, d_residual, d_npoints, d_stop_code,
+                      d_end_ray_vec, d_end_residuals, d_max_residuals, (hipStream_t)hip_stream, flags,
+                      TraceExtras());
+}
+
+// ray_scan fused into one launch (ray_scan.f90:33-49, scanner_m.f90:174-205: scan_parameter = 'ds').
+int rays_hip_scan_device(const rays_params_t* p, int n_runs, const double* d_ds_values, int nray,
+                         const double* d_rvec0, const double* d_rindex_vec0, double* d_ray_vec,
+                         double* d_residual, int32_t* d_npoints, int32_t* d_stop_code, double* d_end_ray_vec,
+                         double* d_end_residuals, double* d_max_residuals, void* hip_stream, int flags) {
+  int rc = rays_hip_check_params(p);
+  if (rc) return rc;
+  if (n_runs < 0 || nray < 0) return fail("rays_hip_scan_device: n_runs, nray < 0");
+  if (n_runs == 0 || nray == 0) return 0;
+  if ((long long)n_runs * nray > 0x7fffffffll) return fail("rays_hip_scan_device: n_runs * nray exceeds 2^31 - 1");
+  if (!d_ds_values || !d_rvec0 || !d_rindex_vec0 || !d_ray_vec || !d_residual || !d_npoints || !d_stop_code)
+    return fail("rays_hip_scan_device: null device pointer");
+  TraceExtras x;
+  x.ds_run = d_ds_values;
+  x.rays_per_run = nray;
+  return launch_trace(p, n_runs * nray, d_rvec0, d_rindex_vec0, d_ray_vec, d_residual, d_npoints, d_stop_code,
+                      d_end_ray_vec, d_end_residuals, d_max_residuals, (hipStream_t)hip_stream, flags, x);
+}
+
+// Batched `call ode_solver(eqn_ray, nv, v, s, sout, ray_stop)` (ode_m.f90:218-254) + the check_save that
+// trace_rays applies to its result (ray_tracing.f90:212-243): one output step from n arbitrary states.
+// Runs the trace kernels with nstep_max = 1 from the caller's v0 / s0 and picks point 2 of each ray.
+namespace rays {
+__global__ void ode_step_collect_kernel(int n, int nv, const double* __restrict__ ray_vec,
+                                        const double* __restrict__ residual, const int32_t* __restrict__ npoints,
+                                        const int32_t* __restrict__ stop, double* __restrict__ v1,
+                                        double* __restrict__ resid, int32_t* __restrict__ code) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const bool stepped = npoints[r] == 2;  // the step was taken and passed check_save
+  for (int c = 0; c < nv; c++) v1[(long long)r * nv + c] = stepped ? ray_vec[((long long)r * 2 + 1) * nv + c] : 0.;
+  if (resid) resid[r] = stepped ? residual[(long long)r * 2 + 1] : 0.;
+  // a ray that took its one step ends on ' nstep > nstep_max' (or 'sout > s_max'), which is not a stop of this step
+  code[r] = stepped ? RAYS_STOP_NONE : stop[r];
+}
+}  // namespace rays
+
+int rays_hip_ode_step_device(const rays_params_t* p, int n, const double* d_v0, const double* d_s0,
+                             double* d_v1, double* d_resid, int32_t* d_stop_code, void* hip_stream) {
+  int rc = rays_hip_check_params(p);
+  if (rc) return rc;
+  if (n < 0) return fail("rays_hip_ode_step_device: n < 0");
+  if (n == 0) return 0;
+  if (!d_v0 || !d_v1 || !d_stop_code) return fail("rays_hip_ode_step_device: null device pointer");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  rays_params_t q = *p;
+  q.nstep_max = 1;
+  q.s_max = 1.7976931348623157e308;
+  const size_t nv = (size_t)p->nv;
+  double *d_rv = nullptr, *d_res = nullptr;
+  int32_t *d_np = nullptr, *d_sc = nullptr;
+  auto release = [&]() { (void)hipFree(d_rv); (void)hipFree(d_res); (void)hipFree(d_np); (void)hipFree(d_sc); };
+  if (hipMalloc(&d_rv, sizeof(double) * 2 * nv * n) != hipSuccess || hipMalloc(&d_res, sizeof(double) * 2 * n) != hipSuccess ||
+      hipMalloc(&d_np, sizeof(int32_t) * n) != hipSuccess || hipMalloc(&d_sc, sizeof(int32_t) * n) != hipSuccess) {
+    release();
+    return fail("rays_hip_ode_step_device: out of device memory");
+  }
+  TraceExtras x;
+  x.v0 = d_v0;
+  x.s0 = d_s0;
+  // rvec0 / rindex_vec0 are not read when v0 is given; any valid pointer will do
+  rc = launch_trace(&q, n, d_v0, d_v0, d_rv, d_res, d_np, d_sc, nullptr, nullptr, nullptr, stream,
+                    RAYS_TRACE_NO_ZERO_FILL, x);
+  if (rc == 0) {
+    hipLaunchKernelGGL(rays::ode_step_collect_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, (int)nv, d_rv,
+                       d_res, d_np, d_sc, d_v1, d_resid, d_stop_code);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);  // the scratch arrays are released below
+    if (e != hipSuccess) rc = hip_fail(e, "rays_hip_ode_step_device");
+  }
+  release();
+  return rc;
 }
 
 // Device buffers of rays_hip_trace are kept between calls (a host that traces repeatedly -- ray_scan, a
 // time loop -- otherwise pays ~6 ms per call for hipMalloc/hipFree of the 64k fan's 5 GB): a released
 // block goes to its device's free list and serves the next request of a similar size.  Everything is
 // returned to the driver by rays_hip_finalize, or at once when an allocation fails.
+// (One cache per SLOT of the device list rays_hip_init[_devices] selected -- a device may appear in
+// several slots, each with its own host thread, stream and buffers.)
 struct DeviceBlockCache {
   struct Block { void* p; size_t cap; };
+  int device = -1;
   std::mutex mu;
   std::vector<Block> idle;
   std::map<void*, size_t> live;
@@ -449,9 +601,9 @@ struct DeviceBlockCache {
   }
 };
 static DeviceBlockCache g_blocks[16];
-static hipError_t cached_malloc(int dev, void** out, size_t bytes) {
-  if (dev < 0 || dev >= 16) return hipMalloc(out, bytes);
-  DeviceBlockCache& c = g_blocks[dev];
+static hipError_t cached_malloc(int slot, void** out, size_t bytes) {
+  if (slot < 0 || slot >= 16) return hipMalloc(out, bytes);
+  DeviceBlockCache& c = g_blocks[slot];
   std::lock_guard<std::mutex> lk(c.mu);
   size_t best = c.idle.size();
   for (size_t i = 0; i < c.idle.size(); i++)
@@ -473,10 +625,10 @@ static hipError_t cached_malloc(int dev, void** out, size_t bytes) {
   if (e == hipSuccess) c.live[*out] = bytes ? bytes : 1;
   return e;
 }
-static hipError_t cached_stream(int dev, hipStream_t* out, bool* owned) {
-  *owned = dev < 0 || dev >= 16;
+static hipError_t cached_stream(int slot, hipStream_t* out, bool* owned) {
+  *owned = slot < 0 || slot >= 16;
   if (*owned) return hipStreamCreate(out);
-  DeviceBlockCache& c = g_blocks[dev];
+  DeviceBlockCache& c = g_blocks[slot];
   std::lock_guard<std::mutex> lk(c.mu);
   if (!c.stream) {
     hipError_t e = hipStreamCreate(&c.stream);
@@ -485,10 +637,10 @@ static hipError_t cached_stream(int dev, hipStream_t* out, bool* owned) {
   *out = c.stream;
   return hipSuccess;
 }
-static void cached_free(int dev, void* ptr) {
+static void cached_free(int slot, void* ptr) {
   if (!ptr) return;
-  if (dev < 0 || dev >= 16) { (void)hipFree(ptr); return; }
-  DeviceBlockCache& c = g_blocks[dev];
+  if (slot < 0 || slot >= 16) { (void)hipFree(ptr); return; }
+  DeviceBlockCache& c = g_blocks[slot];
   std::lock_guard<std::mutex> lk(c.mu);
   auto it = c.live.find(ptr);
   if (it == c.live.end()) { (void)hipFree(ptr); return; }
@@ -501,7 +653,7 @@ static void release_cached_device_blocks() {
     DeviceBlockCache& c = g_blocks[d];
     std::lock_guard<std::mutex> lk(c.mu);
     if (c.idle.empty() && !c.stream) continue;
-    (void)hipSetDevice(d);
+    if (c.device >= 0) (void)hipSetDevice(c.device);
     c.drop_idle();
     if (c.stream) (void)hipStreamDestroy(c.stream);
     c.stream = nullptr;
@@ -516,21 +668,25 @@ struct StagingBuffers {
   long long points = 0;
   size_t nv = 0;
 };
-static std::vector<StagingBuffers> g_staging;
-static StagingBuffers* staging_for_device(int dev, size_t nv) {
+// Fixed storage: every device's host thread keeps a pointer into it for the whole copy phase, so
+// the elements must never move (one slot per device ordinal, like g_blocks).
+constexpr int kMaxDevices = 16;
+static StagingBuffers g_staging[kMaxDevices];
+static StagingBuffers* staging_for_slot(int dev, size_t nv, long long min_points) {
+  if (dev < 0 || dev >= kMaxDevices) return nullptr;
   std::lock_guard<std::mutex> lk(g_mu);
-  if ((int)g_staging.size() <= dev) g_staging.resize(dev + 1);
   StagingBuffers& sb = g_staging[dev];
-  if (sb.points == 0 || sb.nv < nv) {
+  if (sb.points == 0 || sb.nv < nv || sb.points < min_points) {
     for (int b = 0; b < 2; b++) {
       if (sb.vec[b]) (void)hipHostFree(sb.vec[b]);
       if (sb.res[b]) (void)hipHostFree(sb.res[b]);
       sb.vec[b] = sb.res[b] = nullptr;
     }
-    const long long pts = 1ll << 20;  // 1 M points per buffer: 8 (nv + 1) MB, e.g. 64 MB for nv = 7
+    // 1 M points per buffer (8 (nv + 1) MB, e.g. 64 MB for nv = 7), and never less than one whole ray
+    const long long pts = std::max(1ll << 20, min_points);
     for (int b = 0; b < 2; b++) {
-      if (hipHostMalloc((void**)&sb.vec[b], sizeof(double) * nv * (size_t)pts, hipHostMallocDefault) != hipSuccess ||
-          hipHostMalloc((void**)&sb.res[b], sizeof(double) * (size_t)pts, hipHostMallocDefault) != hipSuccess) {
+      if (hipHostMalloc((void**)&sb.vec[b], sizeof(double) * nv * (size_t)pts, hipHostMallocPortable) != hipSuccess ||
+          hipHostMalloc((void**)&sb.res[b], sizeof(double) * (size_t)pts, hipHostMallocPortable) != hipSuccess) {
         sb.points = 0;
         return nullptr;
       }
@@ -542,7 +698,7 @@ static StagingBuffers* staging_for_device(int dev, size_t nv) {
 }
 
 // One device's share of rays_hip_trace: rays [r0, r1) -> contiguous slabs of the host arrays.
-static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1, const double* rvec0,
+static int trace_block_on_device(int slot, int dev, const rays_params_t* p, int r0, int r1, const double* rvec0,
                                  const double* rindex_vec0, double* ray_vec, double* residual,
                                  int32_t* npoints, int32_t* stop_code, double* end_ray_vec,
                                  double* end_residuals, double* max_residuals, std::string* err) {
@@ -568,9 +724,21 @@ static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1
     t_prev = now;
   };
   DEV_TRY(hipSetDevice(dev));
+  if (slot >= 0 && slot < 16) {  // a slot that moved to another device gives its cached buffers back first
+    DeviceBlockCache& c = g_blocks[slot];
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (c.device >= 0 && c.device != dev) {
+      (void)hipSetDevice(c.device);
+      c.drop_idle();
+      if (c.stream) (void)hipStreamDestroy(c.stream);
+      c.stream = nullptr;
+      (void)hipSetDevice(dev);
+    }
+    c.device = dev;
+  }
   hipStream_t st;
   bool own_stream = false;
-  DEV_TRY(cached_stream(dev, &st, &own_stream));
+  DEV_TRY(cached_stream(slot, &st, &own_stream));
   lap("stream");
   double *d_r = nullptr, *d_n = nullptr, *d_rv = nullptr, *d_res = nullptr, *d_ev = nullptr, *d_er = nullptr,
          *d_mr = nullptr;
@@ -585,15 +753,15 @@ static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1
       break;                                 \
     }                                        \
   }
-    DEV_CHK(cached_malloc(dev, (void**)&d_r, sizeof(double) * 3 * n));
-    DEV_CHK(cached_malloc(dev, (void**)&d_n, sizeof(double) * 3 * n));
-    DEV_CHK(cached_malloc(dev, (void**)&d_rv, sizeof(double) * npt * nv * n));
-    DEV_CHK(cached_malloc(dev, (void**)&d_res, sizeof(double) * npt * n));
-    DEV_CHK(cached_malloc(dev, (void**)&d_np, sizeof(int32_t) * n));
-    DEV_CHK(cached_malloc(dev, (void**)&d_sc, sizeof(int32_t) * n));
-    DEV_CHK(cached_malloc(dev, (void**)&d_ev, sizeof(double) * nv * n));
-    DEV_CHK(cached_malloc(dev, (void**)&d_er, sizeof(double) * n));
-    DEV_CHK(cached_malloc(dev, (void**)&d_mr, sizeof(double) * n));
+    DEV_CHK(cached_malloc(slot, (void**)&d_r, sizeof(double) * 3 * n));
+    DEV_CHK(cached_malloc(slot, (void**)&d_n, sizeof(double) * 3 * n));
+    DEV_CHK(cached_malloc(slot, (void**)&d_rv, sizeof(double) * npt * nv * n));
+    DEV_CHK(cached_malloc(slot, (void**)&d_res, sizeof(double) * npt * n));
+    DEV_CHK(cached_malloc(slot, (void**)&d_np, sizeof(int32_t) * n));
+    DEV_CHK(cached_malloc(slot, (void**)&d_sc, sizeof(int32_t) * n));
+    DEV_CHK(cached_malloc(slot, (void**)&d_ev, sizeof(double) * nv * n));
+    DEV_CHK(cached_malloc(slot, (void**)&d_er, sizeof(double) * n));
+    DEV_CHK(cached_malloc(slot, (void**)&d_mr, sizeof(double) * n));
     lap("device allocations");
     DEV_CHK(hipMemcpyAsync(d_r, rvec0 + 3 * (size_t)r0, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
     DEV_CHK(hipMemcpyAsync(d_n, rindex_vec0 + 3 * (size_t)r0, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
@@ -620,15 +788,15 @@ static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1
       const long long total = offs[n];
       long long* d_off = nullptr;
       double *d_pv = nullptr, *d_pr = nullptr;
-      DEV_CHK(cached_malloc(dev, (void**)&d_off, sizeof(long long) * ((size_t)n + 1)));
+      DEV_CHK(cached_malloc(slot, (void**)&d_off, sizeof(long long) * ((size_t)n + 1)));
       bool ok = true;
       do {
         if (total == 0) break;
-        if (cached_malloc(dev, (void**)&d_pv, sizeof(double) * nv * (size_t)total) != hipSuccess ||
-            cached_malloc(dev, (void**)&d_pr, sizeof(double) * (size_t)total) != hipSuccess) { ok = false; break; }
+        if (cached_malloc(slot, (void**)&d_pv, sizeof(double) * nv * (size_t)total) != hipSuccess ||
+            cached_malloc(slot, (void**)&d_pr, sizeof(double) * (size_t)total) != hipSuccess) { ok = false; break; }
         if (hipMemcpyAsync(d_off, offs.data(), sizeof(long long) * ((size_t)n + 1), hipMemcpyHostToDevice, st) != hipSuccess) { ok = false; break; }
         if (rays::launch_pack(true, n, (int)nv, p->nstep_max, d_np, d_off, d_rv, d_res, d_pv, d_pr, st) != hipSuccess) { ok = false; break; }
-        StagingBuffers* sb = staging_for_device(dev, nv);
+        StagingBuffers* sb = staging_for_slot(slot, nv, (long long)npt);
         if (!sb) { ok = false; break; }
         // chunks of rays whose packed size fits one staging buffer
         int c0 = 0, buf = 0;
@@ -657,7 +825,7 @@ static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1
         while (c0 < n && ok) {
           int c1 = c0;
           while (c1 < n && offs[(size_t)c1 + 1] - offs[c0] <= sb->points) c1++;
-          if (c1 == c0) c1 = c0 + 1;  // (cannot happen: a ray has at most nstep_max+1 <= sb->points points)
+          if (c1 == c0) { ok = false; break; }  // a ray has at most nstep_max+1 <= sb->points points (staging_for_slot)
           const long long pts = offs[c1] - offs[c0];
           if (pts > 0) {
             if (hipMemcpyAsync(sb->vec[buf], d_pv + offs[c0] * (long long)nv, sizeof(double) * nv * (size_t)pts,
@@ -679,7 +847,7 @@ static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1
         (void)hipEventDestroy(ev[0]);
         (void)hipEventDestroy(ev[1]);
       } while (0);
-      cached_free(dev, d_off); cached_free(dev, d_pv); cached_free(dev, d_pr);
+      cached_free(slot, d_off); cached_free(slot, d_pv); cached_free(slot, d_pr);
       lap("pack + copy + host scatter");
       if (!ok) {
         rc = bail(fail("rays_hip_trace: packed device-to-host copy failed (out of memory?)"));
@@ -693,8 +861,8 @@ static int trace_block_on_device(int dev, const rays_params_t* p, int r0, int r1
     DEV_CHK(hipStreamSynchronize(st));
   } while (0);
   lap("summaries");
-  cached_free(dev, d_r); cached_free(dev, d_n); cached_free(dev, d_rv); cached_free(dev, d_res); cached_free(dev, d_np);
-  cached_free(dev, d_sc); cached_free(dev, d_ev); cached_free(dev, d_er); cached_free(dev, d_mr);
+  cached_free(slot, d_r); cached_free(slot, d_n); cached_free(slot, d_rv); cached_free(slot, d_res); cached_free(slot, d_np);
+  cached_free(slot, d_sc); cached_free(slot, d_ev); cached_free(slot, d_er); cached_free(slot, d_mr);
   if (own_stream) (void)hipStreamDestroy(st);
   lap("device frees");
   return rc;
@@ -731,7 +899,7 @@ int rays_hip_trace(const rays_params_t* p, int nray, const double* rvec0, const 
   for (int g = 0; g < G; g++) {
     const int r0 = std::min(nray, g * per), r1 = std::min(nray, (g + 1) * per);
     th.emplace_back([&, g, r0, r1] {
-      rcs[g] = trace_block_on_device(devs[g], p, r0, r1, rvec0, rindex_vec0, ray_vec, residual, npoints,
+      rcs[g] = trace_block_on_device(g, devs[g], p, r0, r1, rvec0, rindex_vec0, ray_vec, residual, npoints,
                                      stop_code, end_ray_vec, end_residuals, max_residuals, &errs[g]);
     });
   }
@@ -965,27 +1133,36 @@ int rays_hip_probe(const rays_params_t* p, int n, const double* v, double* cold7
   const size_t nv = (size_t)p->nv;
   double *d_v = nullptr, *d_c = nullptr, *d_n = nullptr, *d_f = nullptr, *d_r = nullptr;
   int* d_k = nullptr;
-  HIP_TRY(hipMalloc(&d_v, sizeof(double) * nv * n));
-  HIP_TRY(hipMalloc(&d_c, sizeof(double) * 7 * n));
-  HIP_TRY(hipMalloc(&d_n, sizeof(double) * 7 * n));
-  HIP_TRY(hipMalloc(&d_f, sizeof(double) * nv * n));
-  HIP_TRY(hipMalloc(&d_r, sizeof(double) * n));
-  HIP_TRY(hipMalloc(&d_k, sizeof(int) * 4 * n));
-  HIP_TRY(hipMemcpy(d_v, v, sizeof(double) * nv * n, hipMemcpyHostToDevice));
+  auto release = [&]() {
+    (void)hipFree(d_v); (void)hipFree(d_c); (void)hipFree(d_n); (void)hipFree(d_f); (void)hipFree(d_r); (void)hipFree(d_k);
+  };
+#define PROBE_TRY(call)                                                  \
+  do {                                                                   \
+    hipError_t e_ = (call);                                              \
+    if (e_ != hipSuccess) { release(); return hip_fail(e_, #call); }     \
+  } while (0)
+  PROBE_TRY(hipMalloc(&d_v, sizeof(double) * nv * n));
+  PROBE_TRY(hipMalloc(&d_c, sizeof(double) * 7 * n));
+  PROBE_TRY(hipMalloc(&d_n, sizeof(double) * 7 * n));
+  PROBE_TRY(hipMalloc(&d_f, sizeof(double) * nv * n));
+  PROBE_TRY(hipMalloc(&d_r, sizeof(double) * n));
+  PROBE_TRY(hipMalloc(&d_k, sizeof(int) * 4 * n));
+  PROBE_TRY(hipMemcpy(d_v, v, sizeof(double) * nv * n, hipMemcpyHostToDevice));
   rays::DevParams D = make_dev_params(*p);
   if (p->equilib_model == RAYS_EQ_AXISYM) {
     rc = get_axisym_device(&D);
-    if (rc) return rc;
+    if (rc) { release(); return rc; }
   }
   hipLaunchKernelGGL(rays::probe_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, D, p->equilib_model,
                      p->nspec + 1, p->nv, n, d_v, d_c, d_n, d_f, d_r, d_k);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(cold7, d_c, sizeof(double) * 7 * n, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(num7, d_n, sizeof(double) * 7 * n, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(dvds, d_f, sizeof(double) * nv * n, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(resid, d_r, sizeof(double) * n, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(codes, d_k, sizeof(int) * 4 * n, hipMemcpyDeviceToHost));
-  (void)hipFree(d_v); (void)hipFree(d_c); (void)hipFree(d_n); (void)hipFree(d_f); (void)hipFree(d_r); (void)hipFree(d_k);
+  PROBE_TRY(hipGetLastError());
+  PROBE_TRY(hipMemcpy(cold7, d_c, sizeof(double) * 7 * n, hipMemcpyDeviceToHost));
+  PROBE_TRY(hipMemcpy(num7, d_n, sizeof(double) * 7 * n, hipMemcpyDeviceToHost));
+  PROBE_TRY(hipMemcpy(dvds, d_f, sizeof(double) * nv * n, hipMemcpyDeviceToHost));
+  PROBE_TRY(hipMemcpy(resid, d_r, sizeof(double) * n, hipMemcpyDeviceToHost));
+  PROBE_TRY(hipMemcpy(codes, d_k, sizeof(int) * 4 * n, hipMemcpyDeviceToHost));
+#undef PROBE_TRY
+  release();
   return 0;
 }
 

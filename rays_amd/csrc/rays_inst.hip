@@ -35,13 +35,17 @@ constexpr int DERIV = RAYS_INST_DERIV;
 template <int NS, int NV, int OCC = 1>
 hipError_t launch_one(const DevParams& P, const TraceArgs& A, hipStream_t stream, int* grid_blocks) {
 #if RAYS_INST_SOLVER == 0
-  if (OCC == 2) return launch_persistent(rk4_trace_kernel_w2<EQ, NS, DERIV, NV>, 0, P, A, stream, grid_blocks);
+  // (`if constexpr`: only the listed shapes get a two-waves-per-SIMD build compiled at all)
+  if constexpr (OCC == 2) {
+    return launch_persistent(rk4_trace_kernel_w2<EQ, NS, DERIV, NV>, 0, P, A, stream, grid_blocks);
+  } else {
 #ifdef RAYS_RK4_DIRECT_STORES
-  constexpr size_t lds = 0;
+    constexpr size_t lds = 0;
 #else
-  constexpr size_t lds = PointWindow<NV>::kLdsBytes;  // rays_trace.hpp (0 unless nv = 7 | 8)
+    constexpr size_t lds = PointWindow<NV>::kLdsBytes;  // rays_trace.hpp (0 unless nv = 7 | 8)
 #endif
-  return launch_persistent(rk4_trace_kernel<EQ, NS, DERIV, NV>, lds, P, A, stream, grid_blocks);
+    return launch_persistent(rk4_trace_kernel<EQ, NS, DERIV, NV>, lds, P, A, stream, grid_blocks);
+  }
 #else
   constexpr size_t lds = (size_t)(kBlock / kWave) * SgLds<NV>::kDoublesPerWave * sizeof(double);
   return launch_persistent(sg_trace_kernel<EQ, NS, DERIV, NV>, lds, P, A, stream, grid_blocks);

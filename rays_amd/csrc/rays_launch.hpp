@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <mutex>
 #include <utility>
 
 #include "rays_device.hpp"
@@ -28,19 +29,43 @@ struct KernelEntry {
 
 constexpr int kBlock = 256;
 
-// Occupancy of a kernel on the current device, cached per (kernel, device).  (All trace kernels have
-// the same function type, so the cache must be keyed by the function's address, not by the
-// template instantiation.)
+// Compute units of a device, asked once per process (hipGetDeviceProperties is slow; this sits on the
+// launch path of every trace).
+inline int device_cu_count(int dev) {
+  static std::mutex mu;
+  static int cus[64] = {0};
+  std::lock_guard<std::mutex> lk(mu);
+  if (dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0) {
+    hipDeviceProp_t prop;
+    cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+  }
+  return cus[dev];
+}
+
+// Occupancy of a kernel on the current device, cached per (kernel, device) for the whole process
+// (rays_hip_trace runs each device's share on a fresh host thread, so a thread-local cache would be
+// rebuilt on every call).  All trace kernels have the same function type, so the cache is keyed by
+// the function's address, not by the template instantiation.
 struct Occupancy {
   int blocks_per_cu, cus;
 };
+inline std::mutex& occupancy_mutex() {
+  static std::mutex mu;
+  return mu;
+}
+inline std::map<std::pair<const void*, int>, Occupancy>& occupancy_cache() {
+  static std::map<std::pair<const void*, int>, Occupancy> cache;
+  return cache;
+}
 template <typename Kernel>
 inline hipError_t kernel_occupancy(Kernel kernel, size_t lds_bytes, Occupancy* out) {
-  static thread_local std::map<std::pair<const void*, int>, Occupancy> cache;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   const auto key = std::make_pair(reinterpret_cast<const void*>(kernel), dev);
+  std::lock_guard<std::mutex> lk(occupancy_mutex());
+  auto& cache = occupancy_cache();
   auto it = cache.find(key);
   if (it == cache.end()) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -49,10 +74,7 @@ inline hipError_t kernel_occupancy(Kernel kernel, size_t lds_bytes, Occupancy* o
     int per_cu = 0;
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds_bytes);
     if (e != hipSuccess) return e;
-    hipDeviceProp_t prop;
-    e = hipGetDeviceProperties(&prop, dev);
-    if (e != hipSuccess) return e;
-    it = cache.emplace(key, Occupancy{per_cu > 0 ? per_cu : 1, prop.multiProcessorCount}).first;
+    it = cache.emplace(key, Occupancy{per_cu > 0 ? per_cu : 1, device_cu_count(dev)}).first;
   }
   *out = it->second;
   return hipSuccess;

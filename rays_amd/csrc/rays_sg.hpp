@@ -381,6 +381,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
   int pc = PC_CHECK;
   int nstep = 0;
   double sout = 0.;
+  double ds_ray = P.ds;  // output step of this lane's run (a fused scan gives every run its own)
   double vst[NV];   // v: the ray state at the last completed output point (y of SG_ode)
   double last_resid = 0., prev_resid = 0., maxr = -1.7976931348623157e308;
 
@@ -404,12 +405,11 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
     SG_PROF(0);  // loop overhead, refill
     if (RAYS_RARE(need_init)) {  // ray_tracing.f90:77-93, SG_ode_m.f90:73-85
       const TraceArgs& A = cold_args(A_hot);  // rays_trace.hpp
-      initialize_ode_vector<EQ, NS, NV>(P, A.rvec0 + 3ll * ray, A.rindex_vec0 + 3ll * ray, vst);
+      start_ray<EQ, NS, NV>(P, A, ray, vst, sout, ds_ray);
       pc = PC_CHECK;
       fl |= FL_FIRST;
       nstep = 0;
-      sout = 0.;
-      t = 0.;
+      t = sout;
       last_resid = 0.;
       prev_resid = 0.;
       maxr = -1.7976931348623157e308;
@@ -484,7 +484,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
         }
         if (seg == SEG_DE_BEGIN) {  // ray_tracing.f90:118-172
           t = sout;  // s = sout
-          sout = sout + P.ds;
+          sout = sout + ds_ray;
           tout = sout;
           if (sout > P.s_max) {
             stop = RAYS_STOP_SOUT_GT_SMAX;

@@ -33,7 +33,33 @@ struct TraceArgs {
   double* __restrict__ end_residuals;      // [nray]          (may be null)
   double* __restrict__ max_residuals;      // [nray]          (may be null)
   unsigned int* __restrict__ next_ray;     // refill counter, zeroed before launch
+  // Optional per-ray starting conditions (null = the reference's: v0 from rvec0 / rindex_vec0, s = 0):
+  const double* __restrict__ v0;           // [nray][nv]  full ODE vectors to start from (rays_hip_ode_step_device)
+  const double* __restrict__ s0;           // [nray]      ray parameter at the start
+  // Fused ray_scan (ray_scan.f90:33-49): run r = ray / rays_per_run traces fan member ray % rays_per_run
+  // with step ds_run[r]; rays_per_run = 0: one run, ds from the parameter block.
+  const double* __restrict__ ds_run;       // [nrun]
+  int rays_per_run;
 };
+
+// Start of a ray: initialize_ode_vector (or the caller's v0), the ray parameter and the run's step.
+template <int EQ, int NS, int NV>
+RAYS_DEV void start_ray(const DevParams& P, const TraceArgs& A, int ray, double v[NV], double& s_start, double& ds_ray) {
+  int member = ray;
+  ds_ray = P.ds;
+  if (RAYS_RARE(A.rays_per_run > 0)) {
+    const int run = ray / A.rays_per_run;
+    member = ray - run * A.rays_per_run;
+    ds_ray = A.ds_run[run];
+  }
+  if (RAYS_RARE(A.v0 != nullptr)) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) v[i] = A.v0[(long long)ray * NV + i];
+  } else {
+    initialize_ode_vector<EQ, NS, NV>(P, A.rvec0 + 3ll * member, A.rindex_vec0 + 3ll * member, v);
+  }
+  s_start = A.s0 ? A.s0[ray] : 0.;
+}
 
 // The trace kernels' signature is (DevParams, TraceArgs).  The eleven pointers of TraceArgs are
 // only needed where a ray starts or ends (the two trajectory arrays: where a point is recorded); as plain kernel

@@ -17,9 +17,9 @@ LIB_PATH = os.environ.get("RAYS_HIP_LIB") or os.path.join(_HERE, "lib", "librays
 
 # every symbol include/rays_hip.h declares
 EXPORTED_SYMBOLS = (
-    "rays_hip_init", "rays_hip_finalize", "rays_hip_device_count", "rays_hip_sizeof_params",
+    "rays_hip_init", "rays_hip_init_devices", "rays_hip_finalize", "rays_hip_device_count", "rays_hip_sizeof_params",
     "rays_hip_last_error", "rays_hip_set_zfun_table", "rays_hip_set_axisym_tables",
-    "rays_hip_stop_flag_text", "rays_hip_check_params", "rays_hip_trace", "rays_hip_trace_device",
+    "rays_hip_stop_flag_text", "rays_hip_check_params", "rays_hip_trace", "rays_hip_trace_device", "rays_hip_scan_device", "rays_hip_ode_step_device",
     "rays_hip_kernel_name", "rays_hip_kernel_name_for", "rays_hip_probe", "rays_hip_pack_device", "rays_hip_unpack_device",
     "rays_hip_sizeof_fan", "rays_hip_ray_init", "rays_hip_ray_init_device",
     "rays_hip_set_rho_table", "rays_hip_deposition_device",
@@ -46,6 +46,8 @@ def load():
     pp = C.POINTER(RaysParams)
     lib.rays_hip_init.restype = C.c_int
     lib.rays_hip_init.argtypes = [C.c_int]
+    lib.rays_hip_init_devices.restype = C.c_int
+    lib.rays_hip_init_devices.argtypes = [C.c_int, C.POINTER(C.c_int)]
     lib.rays_hip_finalize.restype = C.c_int
     lib.rays_hip_device_count.restype = C.c_int
     lib.rays_hip_sizeof_params.restype = C.c_int
@@ -69,6 +71,10 @@ def load():
     lib.rays_hip_trace.argtypes = [pp, C.c_int, dp, dp, dp, dp, ip, ip, dp, dp, dp, dp]
     lib.rays_hip_trace_device.restype = C.c_int
     lib.rays_hip_trace_device.argtypes = [pp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
+    lib.rays_hip_scan_device.restype = C.c_int
+    lib.rays_hip_scan_device.argtypes = [pp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
+    lib.rays_hip_ode_step_device.restype = C.c_int
+    lib.rays_hip_ode_step_device.argtypes = [pp, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.rays_hip_pack_device.restype = C.c_int
     lib.rays_hip_pack_device.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     lib.rays_hip_unpack_device.restype = C.c_int
@@ -192,6 +198,13 @@ def deposition_device(p: RaysParams, which: str, n_bins: int, nray: int, d_ray_v
            "rays_hip_deposition_device")
 
 
+def init_devices(device_ids):
+    """rays_hip_init_devices: explicit slot -> device list for trace_host (repeats allowed)."""
+    ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+    if load().rays_hip_init_devices(len(device_ids), ids) < 0:
+        raise RaysHipError("rays_hip_init_devices: " + last_error())
+
+
 def trace_host(p: RaysParams, rvec0, rindex_vec0, ngpu: int = 0, out: dict = None) -> dict:
     """rays_hip_trace: host numpy arrays in / out (the Fortran drop-in entry).  `out`: the result
     arrays of an earlier call over the same fan to write into (the library overwrites points
@@ -201,7 +214,7 @@ def trace_host(p: RaysParams, rvec0, rindex_vec0, ngpu: int = 0, out: dict = Non
     rvec0 = np.ascontiguousarray(rvec0, dtype=np.float64)
     rindex_vec0 = np.ascontiguousarray(rindex_vec0, dtype=np.float64)
     nray, nv, npt = len(rvec0), p.nv, p.nstep_max + 1
-    if lib.rays_hip_init(int(ngpu)) < 0:
+    if ngpu is not None and lib.rays_hip_init(int(ngpu)) < 0:   # None: keep the init_devices() selection
         raise RaysHipError("rays_hip_init: " + last_error())
     ensure_tables(p)
     if out is None:
@@ -232,6 +245,38 @@ def trace_device(p: RaysParams, nray: int, d_rvec0: int, d_rindex_vec0: int, d_r
         d_end_ray_vec or None, d_end_residuals or None, d_max_residuals or None, stream or None,
         0 if zero_fill else 1)
     _check(rc, "rays_hip_trace_device")
+
+
+def scan_device(p: RaysParams, n_runs: int, d_ds_values: int, nray: int, d_rvec0: int, d_rindex_vec0: int,
+                d_ray_vec: int, d_residual: int, d_npoints: int, d_stop_code: int, d_end_ray_vec: int = 0,
+                d_end_residuals: int = 0, d_max_residuals: int = 0, stream: int = 0, zero_fill: bool = True):
+    """rays_hip_scan_device: all runs of a `ds` scan in ONE launch (outputs carry a leading run dimension)."""
+    ensure_tables(p)
+    rc = load().rays_hip_scan_device(
+        C.byref(p), int(n_runs), d_ds_values, int(nray), d_rvec0, d_rindex_vec0, d_ray_vec, d_residual,
+        d_npoints, d_stop_code, d_end_ray_vec or None, d_end_residuals or None, d_max_residuals or None,
+        stream or None, 0 if zero_fill else 1)
+    _check(rc, "rays_hip_scan_device")
+
+
+def ode_step(p: RaysParams, v0, s0=None):
+    """rays_hip_ode_step_device on host arrays (through torch device buffers): one output step of the
+    configured ODE solver + check_save from each state v0[n][nv].  Returns (v1, resid, stop_code)."""
+    import torch
+
+    ensure_tables(p)
+    v0 = np.ascontiguousarray(v0, dtype=np.float64).reshape(-1, p.nv)
+    n = len(v0)
+    d_v0 = torch.as_tensor(v0).cuda()
+    d_s0 = None if s0 is None else torch.as_tensor(np.ascontiguousarray(s0, dtype=np.float64)).cuda()
+    d_v1 = torch.zeros((n, p.nv), dtype=torch.float64, device="cuda")
+    d_res = torch.zeros(n, dtype=torch.float64, device="cuda")
+    d_sc = torch.zeros(n, dtype=torch.int32, device="cuda")
+    rc = load().rays_hip_ode_step_device(C.byref(p), n, d_v0.data_ptr(), None if d_s0 is None else d_s0.data_ptr(),
+                                         d_v1.data_ptr(), d_res.data_ptr(), d_sc.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream or None)
+    _check(rc, "rays_hip_ode_step_device")
+    return d_v1.cpu().numpy(), d_res.cpu().numpy(), d_sc.cpu().numpy()
 
 
 def pack_device(nray, nv, nstep_max, d_npoints, d_offsets, d_ray_vec, d_residual, d_packed_vec,

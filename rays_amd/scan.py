@@ -1,14 +1,11 @@
 """Fused `ray_scan`: the reference's scan driver re-initialises and calls
 `trace_rays` once per scan value, serially (RAYS_project/ray_scan/ray_scan.f90:33-49, scanner_m.f90:
 100-205; the scanned parameter is the step size `ds`).  A scan is just more independent rays: here
-every scan value gets its own parameter block and output arrays and all runs are launched
-back-to-back on separate HIP streams, so small fans (a 1024-ray fan occupies 16 of the GPU's 1024
-SIMDs) fill the machine together.  Results per run are exactly those of a stand-alone trace.
-
-How many runs really overlap is set by the HIP runtime's hardware queues: 4 by default.  With
-GPU_MAX_HW_QUEUES=16 in the environment BEFORE the process first touches the GPU, 64 runs of the
-1024-ray fan take 16.3 ms instead of 44.9 ms (162 ms one after another; 8 queues: 25.1 ms, 32: slower).
-`HW_QUEUES_ENV` below is that setting; tools/scan_speed.py applies it.
+ALL runs go out as ONE launch of the trace kernel over n_runs x nray rays (rays_hip_scan_device): ray
+i belongs to run i // nray, which sets its step `ds`; the persistent waves and their refill counter
+treat the lot as one fan, so small fans (a 1024-ray fan occupies 16 of the GPU's 1024 SIMDs) fill the
+machine together and 64 runs of a 1024-ray fan cost about one 64k-ray pass.  Results per run are
+exactly those of a stand-alone trace.
 """
 from __future__ import annotations
 
@@ -18,7 +15,6 @@ import numpy as np
 
 from .params import ConfigError, RaysParams, copy_params
 
-HW_QUEUES_ENV = ("GPU_MAX_HW_QUEUES", "16")
 from .trace import DeviceTrace, RayResults
 
 
@@ -40,35 +36,51 @@ def scan_values(scan_algorithm: str, n_runs: int, p_start: float = 0.0, p_incr: 
 
 
 class RayScan:
-    """All runs of a `ds` scan in flight at once."""
+    """All runs of a `ds` scan in one launch; outputs carry a leading run dimension."""
 
     def __init__(self, params: RaysParams, rvec0, rindex_vec0, ds_values: Sequence[float],
-                 scan_parameter: str = "ds"):
+                 scan_parameter: str = "ds", device=None):
         import torch
+
+        from . import hip
 
         if scan_parameter.strip() != "ds":  # scanner_m.f90:185-201 ('*_num_threads' has no meaning here)
             raise ConfigError(f"initialize_scanner_m: unknown scan parameter = {scan_parameter!r}")
-        self.torch = torch
-        self.runs: List[DeviceTrace] = []
-        for v in ds_values:
-            q = copy_params(params)
-            q.ds = float(v)
-            self.runs.append(DeviceTrace(q, rvec0, rindex_vec0))
-        self.streams = [torch.cuda.Stream() for _ in self.runs]
+        self.torch, self.hip = torch, hip
+        self.params = params
+        hip.check_params(params)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.ds_values = np.ascontiguousarray(ds_values, dtype=np.float64)
+        self.n_runs, self.nray = len(self.ds_values), len(rvec0)
+        nv, npt = params.nv, params.nstep_max + 1
+        f64, i32 = torch.float64, torch.int32
+        R, N = self.n_runs, self.nray
+        with torch.cuda.device(self.device):
+            self.ds = torch.as_tensor(self.ds_values).to(self.device)
+            self.rvec0 = torch.as_tensor(np.ascontiguousarray(rvec0), dtype=f64).to(self.device)
+            self.rindex_vec0 = torch.as_tensor(np.ascontiguousarray(rindex_vec0), dtype=f64).to(self.device)
+            self.ray_vec = torch.zeros((R, N, npt, nv), dtype=f64, device=self.device)
+            self.residual = torch.zeros((R, N, npt), dtype=f64, device=self.device)
+            self.npoints = torch.zeros((R, N), dtype=i32, device=self.device)
+            self.stop_code = torch.zeros((R, N), dtype=i32, device=self.device)
+            self.end_ray_vec = torch.zeros((R, N, nv), dtype=f64, device=self.device)
+            self.end_residuals = torch.zeros((R, N), dtype=f64, device=self.device)
+            self.max_residuals = torch.zeros((R, N), dtype=f64, device=self.device)
 
     def launch(self, zero_fill: bool = True):
-        t = self.torch
-        ready = t.cuda.Event()
-        ready.record()
-        for s, r in zip(self.streams, self.runs):
-            s.wait_event(ready)
-            with t.cuda.stream(s):
-                r.launch(zero_fill=zero_fill)
+        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        self.hip.scan_device(self.params, self.n_runs, self.ds.data_ptr(), self.nray, self.rvec0.data_ptr(),
+                             self.rindex_vec0.data_ptr(), self.ray_vec.data_ptr(), self.residual.data_ptr(),
+                             self.npoints.data_ptr(), self.stop_code.data_ptr(), self.end_ray_vec.data_ptr(),
+                             self.end_residuals.data_ptr(), self.max_residuals.data_ptr(), stream=stream,
+                             zero_fill=zero_fill)
 
     def synchronize(self):
-        for s in self.streams:
-            s.synchronize()
+        self.torch.cuda.synchronize(self.device)
 
     def results(self) -> List[RayResults]:
         self.synchronize()
-        return [r.results() for r in self.runs]
+        c = lambda x: x.cpu().numpy()
+        arrays = [c(a) for a in (self.ray_vec, self.residual, self.npoints, self.stop_code, self.end_ray_vec,
+                                 self.end_residuals, self.max_residuals)]
+        return [RayResults(*(a[r] for a in arrays)) for r in range(self.n_runs)]

@@ -15,7 +15,8 @@ GOLDEN_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_n
                 "gold_solovev64_sg_cold", "gold_solovev64_sg_num", "gold_solovev64_arcl_grad_sg", "gold_solovev64_slow_sg", "gold_slab16_fast_rk4", "gold_slab16_damp_rk4", "gold_slab_box_exits_rk4", "gold_slab_negative_temp_rk4", "gold_slab_negative_dens_rk4",
                 "gold_solovev64_damp_rk4", "gold_solovev64_damp_sg", "gold_axisym64_eqdsk_damp_rk4",
                 "gold_axisym64_eqdsk_damp_sg", "gold_axisym64_eqdsk_tspline_rk4_num", "gold_axisym16_eqdsk_zexit_rk4",
-                "gold_slab_toroid_parab_arcl_grad_rk4", "gold_slab_shear_gauss_3spec_sg_num", "gold_slab_lin2_rk4_num"]
+                "gold_slab_toroid_parab_arcl_grad_rk4", "gold_slab_shear_gauss_3spec_sg_num", "gold_slab_lin2_rk4_num",
+                "gold_slab_ns1_rk4", "gold_solovev64_damp_grad_rk4"]
 
 
 def load_golden(name):
@@ -59,10 +60,22 @@ def assert_matches_golden(out, g, p, rel_tol=1e-10, resid_atol=1e-12, exact=Fals
     assert worst <= rel_tol, f"trajectory rel err {worst:.3e} > {rel_tol}"
     d7 = np.abs(rv[..., 6] - ref[..., 6])
     assert (d7 <= rel_tol * np.maximum(np.abs(ref[..., 6]), 1e-30) + 1e-300).all()
-    if rv.shape[-1] > 7:
-        # v(8) = absorbed power fraction: the reference carries it through single-precision
-        # COMPLEX temporaries (damp_fund_ECH.f90:36), i.e. ~7 significant digits
-        np.testing.assert_allclose(rv[..., 7:], ref[..., 7:], rtol=1e-6, atol=1e-9)
+    damp = bool(p.damping_model)
+    if damp:
+        # v(8) = absorbed power fraction.  The reference carries k_i through single-precision COMPLEX
+        # temporaries (damp_fund_ECH.f90:36: D_WARM, DELTA), and Im Z = sqrt(pi) exp(-xi^2) is a libm exp:
+        # an ulp of difference between ocml's and glibc's exp can flip the float rounding, i.e. move k_i by
+        # a single-precision ulp (6e-8).  Hence 1e-6 on this row only (observed: bit-identical for RK4).
+        np.testing.assert_allclose(rv[..., 7], ref[..., 7], rtol=1e-6, atol=1e-9)
+    g0 = 8 if damp else 7
+    if rv.shape[-1] > g0:
+        # integrate_eq_gradients rows (eqn_ray.f90:217-229): plain double precision like r and k, so the same
+        # bar: 1e-10 relative to the row's magnitude along the ray (they cross zero, so not element-wise)
+        d = np.abs(rv[..., g0:] - ref[..., g0:])
+        scale = np.maximum(np.abs(ref[..., g0:]).max(axis=1, keepdims=True), 1e-300)
+        gw = float((d / scale).max())
+        assert gw <= rel_tol, f"equilibrium-gradient rows rel err {gw:.3e} > {rel_tol}"
+        worst = max(worst, gw)
     np.testing.assert_allclose(out["residual"][:, :keep], g["residual"], rtol=0, atol=resid_atol)
     # zero beyond npoints (ray_results_m.f90:154-164)
     for r, n in enumerate(g["npoints"]):

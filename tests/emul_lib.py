@@ -61,6 +61,9 @@ def _load(path):
         dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
         _lib.rays_emul_trace.restype = C.c_int
         _lib.rays_emul_trace.argtypes = [C.POINTER(RaysParams), C.c_int, dp, dp, dp, dp, ip, ip, dp, dp, dp]
+        _lib.rays_emul_trace_ex.restype = C.c_int
+        _lib.rays_emul_trace_ex.argtypes = [C.POINTER(RaysParams), C.c_int, dp, dp, dp, dp, ip, ip, dp, dp, dp,
+                                            dp, dp, dp, C.c_int]
         _lib.rays_emul_set_zfun_table.restype = C.c_int
         _lib.rays_emul_set_zfun_table.argtypes = [dp, C.c_int, C.c_double, C.c_double]
         _set_zfun(_lib.rays_emul_set_zfun_table)
@@ -117,6 +120,53 @@ def trace(p: RaysParams, rvec0, rindex_vec0, small_tiers: bool = False, vec_offs
     if rc:
         raise RuntimeError(f"rays_emul_trace rc={rc}")
     return out
+
+
+def _out(nray, nv, npt):
+    return dict(ray_vec=np.zeros((nray, npt, nv)), residual=np.zeros((nray, npt)),
+                npoints=np.zeros(nray, dtype=np.int32), stop_code=np.zeros(nray, dtype=np.int32),
+                end_ray_vec=np.zeros((nray, nv)), end_residuals=np.zeros(nray), max_residuals=np.zeros(nray))
+
+
+def _trace_ex(p, nray, rvec0, rindex_vec0, out, v0=None, s0=None, ds_run=None, rays_per_run=0):
+    dp = C.POINTER(C.c_double)
+    d = lambda a: None if a is None else a.ctypes.data_as(dp)
+    i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    rc = lib().rays_emul_trace_ex(C.byref(p), nray, d(rvec0), d(rindex_vec0), d(out["ray_vec"]), d(out["residual"]),
+                                  i(out["npoints"]), i(out["stop_code"]), d(out["end_ray_vec"]),
+                                  d(out["end_residuals"]), d(out["max_residuals"]), d(v0), d(s0), d(ds_run),
+                                  int(rays_per_run))
+    if rc:
+        raise RuntimeError(f"rays_emul_trace_ex rc={rc}")
+
+
+def scan(p: RaysParams, rvec0, rindex_vec0, ds_values) -> dict:
+    """The fused scan's launch (rays_hip_scan_device: run = ray // nray, ds per run) through the kernel source on
+    the host; arrays carry a leading run dimension."""
+    rvec0 = np.ascontiguousarray(rvec0, dtype=np.float64)
+    rindex_vec0 = np.ascontiguousarray(rindex_vec0, dtype=np.float64)
+    ds = np.ascontiguousarray(ds_values, dtype=np.float64)
+    nray, R = len(rvec0), len(ds)
+    out = _out(R * nray, p.nv, p.nstep_max + 1)
+    _trace_ex(p, R * nray, rvec0, rindex_vec0, out, ds_run=ds, rays_per_run=nray)
+    return {k: v.reshape((R, nray) + v.shape[1:]) for k, v in out.items()}
+
+
+def ode_step(p: RaysParams, v0, s0=None):
+    """rays_hip_ode_step_device's launch (nstep_max = 1 from the caller's states) on the host:
+    (v1, resid, stop_code) with stop_code 0 where the step was taken and kept."""
+    from rays_amd.params import copy_params
+    v0 = np.ascontiguousarray(v0, dtype=np.float64).reshape(-1, p.nv)
+    s0 = None if s0 is None else np.ascontiguousarray(s0, dtype=np.float64)
+    q = copy_params(p)
+    q.nstep_max = 1
+    q.s_max = 1.7976931348623157e308
+    n = len(v0)
+    out = _out(n, p.nv, 2)
+    _trace_ex(q, n, v0, v0, out, v0=v0, s0=s0)
+    ok = out["npoints"] == 2
+    return (np.where(ok[:, None], out["ray_vec"][:, 1], 0.0), np.where(ok, out["residual"][:, 1], 0.0),
+            np.where(ok, 0, out["stop_code"]).astype(np.int32))
 
 
 def ray_init(p: RaysParams, fan: RaysFan, nray_max: int):

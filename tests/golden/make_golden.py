@@ -64,7 +64,24 @@ CASES = [
     ("gold_slab_toroid_parab_arcl_grad_rk4", "gold_slab_toroid_parab_arcl_grad_rk4.in", None, 30, 120),
     ("gold_slab_shear_gauss_3spec_sg_num", "gold_slab_shear_gauss_3spec_sg_num.in", None, 0, 0),
     ("gold_slab_lin2_rk4_num", "gold_slab_lin2_rk4_num.in", None, 25, 60),
+    # kernel shapes no other fixture instantiates: electrons only (nspec = 0 -> NS = 1; the reference needs
+    # `neutrality` relaxed for that) and damping + integrate_eq_gradients (nv = 13)
+    ("gold_slab_ns1_rk4", "gold_slab_ns1_rk4.in", None, 25, 60),
+    ("gold_solovev64_damp_grad_rk4", "gold_solovev64_damp_grad_rk4.in", list(range(0, 64, 5)), 0, 0),
 ]
+
+
+def check_deterministic(cfg):
+    """The reference's Z-function spline keeps SAVEd work arrays (zfunctions_m.f90:378,393) and
+    deriv_num rewrites module variables (deriv_num.f90:6-10): under the OpenMP ray loop both race and the
+    output varies from run to run.  A fixture of such a config must be cut from a one-thread run."""
+    from rays_amd.namelist import read_namelist
+    nml = read_namelist(os.path.join(ROOT, "configs", cfg))
+    racy = str(nml.get("damping_list", {}).get("damping_model", "no_damp")).strip() != "no_damp" or \
+        str(nml.get("ode_list", {}).get("ray_deriv_name", "cold")).strip() == "numerical"
+    if racy and int(nml.get("openmp_list", {}).get("num_threads", 0)) != 1:
+        sys.exit(f"configs/{cfg}: damping / numerical-derivative configs need `&openmp_list num_threads = 1 /` "
+                 "(the reference races otherwise and the fixture would not be reproducible)")
 
 
 def results_file_fixture():
@@ -88,6 +105,7 @@ def main():
     for name, cfg, subset, stride, nprobe in CASES:
         if only and name not in only:
             continue
+        check_deterministic(cfg)
         with tempfile.TemporaryDirectory() as d:
             shutil.copy(os.path.join(ROOT, "configs", cfg), os.path.join(d, "rays.in"))
             for f in os.listdir(os.path.join(ROOT, "configs")):

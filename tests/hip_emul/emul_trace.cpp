@@ -12,8 +12,8 @@ RAYS_EMUL_DEFINE_GLOBALS
 #include "emul_dev_params.inc"
 #include "../../rays_amd/csrc/rays_fan_setup.inc"
 
-// Instantiated here: two species with nv = 7 | 8 for every equilibrium; nv = 12 (integrate_eq_gradients)
-// for the slab and Solovev; for the slab also nv = 13 and three species (nv = 7).
+// Instantiated here: two species with nv = 7 | 8 for every equilibrium; nv = 12 | 13 (integrate_eq_gradients)
+// for the slab and Solovev; for the slab also one and three species (nv = 7).
 template <int EQ, int DERIV, int NS, int NV>
 static int run1(int solver, const rays::DevParams& D, const rays::TraceArgs& A) {
   threadIdx.x = 0; blockIdx.x = 0; blockDim.x = 1; gridDim.x = 1;
@@ -27,9 +27,10 @@ static int run(int solver, int ns, int nv, const rays::DevParams& D, const rays:
   if (ns == 2 && nv == 8) return run1<EQ, DERIV, 2, 8>(solver, D, A);
   if constexpr ((EQ & 3) != 2) {
     if (ns == 2 && nv == 12) return run1<EQ, DERIV, 2, 12>(solver, D, A);
+    if (ns == 2 && nv == 13) return run1<EQ, DERIV, 2, 13>(solver, D, A);
   }
   if constexpr ((EQ & 3) == 0) {
-    if (ns == 2 && nv == 13) return run1<EQ, DERIV, 2, 13>(solver, D, A);
+    if (ns == 1 && nv == 7) return run1<EQ, DERIV, 1, 7>(solver, D, A);
     if (ns == 3 && nv == 7) return run1<EQ, DERIV, 3, 7>(solver, D, A);
   }
   return 1;
@@ -57,12 +58,28 @@ extern "C" int rays_emul_set_axisym_tables(const rays_axisym_tables_t* t) {
   return 0;
 }
 
+// nray = total rays of the launch.  v0 / s0: optional starting states (rays_hip_ode_step_device);
+// ds_run / rays_per_run: a fused `ds` scan (rays_hip_scan_device).
+extern "C" int rays_emul_trace_ex(const rays_params_t* p, int nray, const double* rvec0,
+                                  const double* rindex_vec0, double* ray_vec, double* residual,
+                                  int32_t* npoints, int32_t* stop_code, double* end_ray_vec,
+                                  double* end_residuals, double* max_residuals, const double* v0,
+                                  const double* s0, const double* ds_run, int rays_per_run);
 extern "C" int rays_emul_trace(const rays_params_t* p, int nray, const double* rvec0,
                                const double* rindex_vec0, double* ray_vec, double* residual,
                                int32_t* npoints, int32_t* stop_code, double* end_ray_vec,
                                double* end_residuals, double* max_residuals) {
+  return rays_emul_trace_ex(p, nray, rvec0, rindex_vec0, ray_vec, residual, npoints, stop_code, end_ray_vec,
+                            end_residuals, max_residuals, nullptr, nullptr, nullptr, 0);
+}
+extern "C" int rays_emul_trace_ex(const rays_params_t* p, int nray, const double* rvec0,
+                                  const double* rindex_vec0, double* ray_vec, double* residual,
+                                  int32_t* npoints, int32_t* stop_code, double* end_ray_vec,
+                                  double* end_residuals, double* max_residuals, const double* v0,
+                                  const double* s0, const double* ds_run, int rays_per_run) {
   unsigned counter = 0;
-  rays::TraceArgs A;
+  rays::TraceArgs A = rays::TraceArgs();
+  A.v0 = v0; A.s0 = s0; A.ds_run = ds_run; A.rays_per_run = rays_per_run;
   A.nray = nray; A.rvec0 = rvec0; A.rindex_vec0 = rindex_vec0; A.ray_vec = ray_vec;
   A.residual = residual; A.npoints = npoints; A.stop_code = stop_code; A.end_ray_vec = end_ray_vec;
   A.end_residuals = end_residuals; A.max_residuals = max_residuals; A.next_ray = &counter;
@@ -92,12 +109,15 @@ extern "C" int rays_emul_trace(const rays_params_t* p, int nray, const double* r
 // Ray initialisation (rays_ray_init.hpp: fan_member) run sequentially in the reference's loop order.
 template <int EQ>
 static bool emul_member(const rays::DevParams& D, const rays::FanArgs& F, const double* rvec, int ia, int ib, double* ri) {
-  if constexpr (EQ == 0) if (D.nspec == 2) return rays::fan_member<EQ, 3>(D, F, rvec, ia, ib, ri);
+  if constexpr (EQ == 0) {
+    if (D.nspec == 2) return rays::fan_member<EQ, 3>(D, F, rvec, ia, ib, ri);
+    if (D.nspec == 0) return rays::fan_member<EQ, 1>(D, F, rvec, ia, ib, ri);
+  }
   return rays::fan_member<EQ, 2>(D, F, rvec, ia, ib, ri);
 }
 extern "C" int rays_emul_ray_init(const rays_params_t* p, const rays_fan_t* fan, int nray_max, double* rvec0,
                                   double* rindex_vec0, int32_t* nray) {
-  if (p->nspec != 1 && !(p->nspec == 2 && p->equilib_model == 0)) return 1;
+  if (p->nspec != 1 && !((p->nspec == 2 || p->nspec == 0) && p->equilib_model == 0)) return 1;
   rays::FanArgs F;
   std::vector<double> launch;
   int per_r = 0;

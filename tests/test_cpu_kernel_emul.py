@@ -120,3 +120,43 @@ def test_slab_deposition_source_on_host_equals_reference():
     for x in prof:
         q = q + x
     assert q == g["dep_q_sum"][0] and q > 0.05   # 16 rays x 0.99 absorbed x weight 1/256 (App. A-11)
+
+
+def test_fused_scan_launch_equals_oracle_per_run():
+    """rays_hip_scan_device's launch (one fan of n_runs x nray rays, the run sets ds; rays_trace.hpp: start_ray)
+    through the kernel source on the host: every run equals the C restatement's trace with that ds."""
+    from rays_amd.params import copy_params
+    from rays_amd.scan import scan_values
+    from tests import oracle_lib
+    g, nml, p = load_golden("cfg2_solovev1024_rk4")
+    r0, n0 = g["rvec0_full"][::64], g["rindex_vec0_full"][::64]
+    vals = scan_values("fixed_increment", 3, p_start=float(p.ds) * 0.5, p_incr=float(p.ds) * 0.5)
+    out = emul_lib.scan(p, r0, n0, vals)
+    assert len({int(out["npoints"][r].sum()) for r in range(3)}) > 1
+    for r, v in enumerate(vals):
+        q = copy_params(p)
+        q.ds = float(v)
+        ora = oracle_lib.trace(q, r0, n0)
+        for k in ("ray_vec", "residual", "npoints", "stop_code", "end_ray_vec", "end_residuals", "max_residuals"):
+            np.testing.assert_array_equal(out[k][r], ora[k], err_msg=f"run {r}: {k}")
+
+
+@pytest.mark.parametrize("name", ["cfg2_solovev1024_rk4", "gold_solovev64_sg_cold", "gold_solovev64_damp_rk4",
+                                  "gold_solovev64_arcl_grad_sg"])
+def test_one_step_restart_reproduces_the_next_reference_point(name):
+    """rays_hip_ode_step_device's launch on the host (glibc libm, like the reference): restarted from any
+    recorded reference point with its ray parameter, one output step lands on the next recorded point bit for
+    bit -- RK4 and SG (whose integrator is restarted every output interval, SG_ode_m.f90:106-122)."""
+    g, nml, p = load_golden(name)
+    ref, npts = g["ray_vec"], g["npoints"]
+    v0, v1, s0 = [], [], []
+    for r in range(min(len(npts), 6)):
+        n = int(npts[r])
+        if n < 2:
+            continue
+        s = np.concatenate([[0.0], np.cumsum(np.full(n - 1, float(p.ds)))])
+        v0.append(ref[r, :n - 1]); v1.append(ref[r, 1:n]); s0.append(s[:n - 1])
+    v0, v1, s0 = np.concatenate(v0), np.concatenate(v1), np.concatenate(s0)
+    got, resid, code = emul_lib.ode_step(p, v0, s0)
+    assert (code == 0).all()
+    np.testing.assert_array_equal(got, v1)

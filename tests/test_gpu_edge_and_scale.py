@@ -164,49 +164,3 @@ def test_pack_unpack_roundtrip_on_device():
     r = 7
     o, m = int(off[r]), int(npts[r])
     assert torch.equal(pv[o:o + m], tr.ray_vec[r, :m])
-
-
-def test_fused_ray_scan_equals_separate_runs():
-    """Fused ray_scan (SURVEY 8(f) f4): all runs of a ds scan in flight at once on separate streams;
-    every run's results are bit-identical to a stand-alone trace with that ds."""
-    from rays_amd.params import copy_params
-    from rays_amd.scan import RayScan, scan_values
-    g, nml, p = load_golden("cfg2_solovev1024_rk4")
-    r0, n0 = g["rvec0_full"][::8], g["rindex_vec0_full"][::8]     # 128 rays
-    vals = scan_values("fixed_increment", 5, p_start=float(p.ds) * 0.5, p_incr=float(p.ds) * 0.25)
-    scan = RayScan(p, r0, n0, vals)
-    scan.launch()
-    res = scan.results()
-    assert len({int(r.npoints.sum()) for r in res}) > 1           # the runs really differ
-    for v, r in zip(vals, res):
-        q = copy_params(p)
-        q.ds = float(v)
-        ref = hip.trace_host(q, r0, n0, ngpu=1)
-        np.testing.assert_array_equal(r.npoints, ref["npoints"])
-        np.testing.assert_array_equal(r.stop_code, ref["stop_code"])
-        np.testing.assert_array_equal(r.ray_vec, ref["ray_vec"])
-        np.testing.assert_array_equal(r.residual, ref["residual"])
-
-
-def test_large_fan_kernel_build_equals_small_fan_build():
-    """Fans of >= 2 waves per SIMD run the two-waves-per-SIMD build of the RK4 kernel (rays_rk4.hpp: OCC);
-    its results are bit-identical to the one-wave build's (same fan traced in two halves)."""
-    import torch
-    from rays_amd.trace import DeviceTrace
-    g, nml, p = load_golden("cfg2_solovev1024_rk4")
-    q = copy_params(p)
-    q.nstep_max = 24
-    reps = 131072 // len(g["rvec0_full"]) + 1
-    r0 = np.tile(g["rvec0_full"], (reps, 1))[:131072 + 640]
-    n0 = np.tile(g["rindex_vec0_full"], (reps, 1))[:131072 + 640]
-    big = DeviceTrace(q, r0, n0)
-    big.launch()
-    h = len(r0) // 2
-    a, b = DeviceTrace(q, r0[:h], n0[:h]), DeviceTrace(q, r0[h:], n0[h:])
-    a.launch()
-    b.launch()
-    torch.cuda.synchronize()
-    for name in ("ray_vec", "residual", "npoints", "stop_code", "end_ray_vec", "max_residuals"):
-        whole = getattr(big, name)
-        assert torch.equal(whole[:h], getattr(a, name)) and torch.equal(whole[h:], getattr(b, name)), name
-    assert int(big.npoints.sum()) > len(r0)

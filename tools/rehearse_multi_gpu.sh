@@ -1,12 +1,18 @@
 #!/bin/bash
-# Rehearsal of the N-rank bench path on ONE GPU: two ranks share the card and exchange over gloo
-# (RCCL refuses two ranks on one device).  (1) trajectory gather with --verify-gather (compares the
-# gathered arrays with a single-GPU trace of the whole fan); (2) deposition-profile exchange, fast
-# and bit-exact forms.  The RCCL path itself runs only on the driver's multi-GPU node.
+# Rehearsal of the N-rank bench path on ONE GPU: `python bench.py --gpus 2` starts its two ranks itself (no
+# launcher); they share the card and exchange over gloo (RCCL refuses two ranks on one device).
+# (1) trajectory gather with --verify-gather (compares the gathered arrays with a single-GPU trace of the
+# whole fan); (2) deposition-profile exchange, fast and bit-exact forms; (3) the torchrun form the driver uses.
+# The RCCL path itself runs only on the driver's multi-GPU node.
 set -e
 export RAYS_BENCH_SHARE_GPU=1 RAYS_BENCH_BACKEND=gloo
-run() { timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
-  --master-port 29511 bench.py --gpus 2 --steps 3 --warmup 1 "$@"; }
+run() { timeout -k 10 500 python bench.py --gpus 2 --steps 3 --warmup 1 "$@"; }
 run --verify-gather
 run --config $PWD/configs/cfg5b_axisym256k_rk4_damp.in --exchange deposition
 run --config $PWD/configs/cfg5b_axisym256k_rk4_damp.in --exchange deposition --exact-profile
+timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+  --master-port 29511 bench.py --gpus 2 --steps 3 --warmup 1
+# a launcher that starts the wrong number of ranks must be refused, and so must --gpus N without N devices
+if WORLD_SIZE=1 RANK=0 python bench.py --gpus 2 --steps 1 --warmup 0 2>/dev/null; then echo "ERROR: WORLD_SIZE=1 with --gpus 2 accepted"; exit 1; fi
+if RAYS_BENCH_SHARE_GPU= python bench.py --gpus 2 --steps 1 --warmup 0 2>/dev/null; then echo "ERROR: --gpus 2 on one GPU accepted"; exit 1; fi
+echo "rehearsal ok"

@@ -47,4 +47,12 @@ summary = {"command": f"tools/profile_bench.sh ... {args}".strip(), "kernel": ke
            "bench_line": bench, "counters": c, "derived": d,
            "note": "WRITE_SIZE/FETCH_SIZE are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half)"}
 json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+# the entry bench.py reads from profiles/counters.json (merged there by tools/update_counters.py)
+entry = {"kernel": bench["config"]["kernel"], "hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"),
+         "fp64_wave_insts": {k: m(f"SQ_INSTS_VALU_{k.upper()}_F64") for k in ("add", "mul", "fma", "trans")
+                             if m(f"SQ_INSTS_VALU_{k.upper()}_F64") is not None},
+         "valu_insts": m("SQ_INSTS_VALU"), "effective_clock_GHz": d.get("effective_clock_GHz"),
+         "wave_time_parked_in_waitcnt": d.get("wave_time_parked_in_waitcnt"),
+         "kernel_avg_ms_rocprof": stats.get("avg_ns", 0.0) / 1e6 if stats else None}
+json.dump({bench["config"]["workload"]: entry}, open(os.path.join(out, "counters_entry.json"), "w"), indent=1)
 print(json.dumps({"kernel": kernel, "kernel_stats": stats, "derived": d}, indent=1))

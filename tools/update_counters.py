@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Merge per-configuration counter entries (pmc_summary.json files written by tools/summarize_profile.py and
+copied under profiles/rNN/) into profiles/counters.json, which bench.py reads for roofline.traffic and
+roofline_fp64.   python tools/update_counters.py profiles/r02/*_pmc_summary.json"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+path = os.path.join(ROOT, "profiles", "counters.json")
+db = json.load(open(path)) if os.path.exists(path) else {}
+for f in sys.argv[1:]:
+    s = json.load(open(f))
+    c, d, b = s["counters"], s["derived"], s["bench_line"]
+    m = lambda k: c[k]["mean_per_launch"] if k in c else None
+    db[b["config"]["workload"]] = {
+        "kernel": b["config"]["kernel"], "hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"),
+        "fp64_wave_insts": {k: m(f"SQ_INSTS_VALU_{k.upper()}_F64") for k in ("add", "mul", "fma", "trans")
+                            if m(f"SQ_INSTS_VALU_{k.upper()}_F64") is not None},
+        "valu_insts": m("SQ_INSTS_VALU"), "effective_clock_GHz": d.get("effective_clock_GHz"),
+        "wave_time_parked_in_waitcnt": d.get("wave_time_parked_in_waitcnt"),
+        "kernel_avg_ms_rocprof": s.get("kernel_stats", {}).get("avg_ns", 0.0) / 1e6,
+        "source": os.path.relpath(os.path.abspath(f), ROOT) + " (rocprofv3 --pmc, separate passes; FETCH_SIZE x2 on gfx950)"}
+json.dump(db, open(path, "w"), indent=1, sort_keys=True)
+print(json.dumps(db, indent=1))
