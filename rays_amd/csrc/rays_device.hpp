@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/rays_hip.h"
+#include "rays_libm.hpp"
 
 namespace rays {
 
@@ -125,10 +126,10 @@ RAYS_DEV double pow4(double x) { return ((x * x) * x) * x; }  // flang lowers x*
 // flavours selected on the host (rays_capi.hip: unit_exponents()):
 //   UE = true  : every profile exponent in use is exactly 1 -> pow_u<true, Y1> is x (Y1: the call
 //                site's exponent is alpha) or 1 (the call site's exponent is alpha - 1); no pow code.
-//   UE = false : general exponents, ocml pow (agrees with glibc's to an ulp).
-// Keeping ocml's pow (~400 instructions, inlined at eight call sites) out of the unit-exponent
-// kernels is worth 15 % on the 64k fan although the code is never executed there: it pushes the
-// kernel past 256 VGPRs and adds SGPR spills in the hot loop.
+//   UE = false : general exponents, libm::pow (rays_libm.hpp: glibc's pow, bit for bit).
+// Keeping pow (eight inlined call sites) out of the unit-exponent kernels is worth 15 % on the 64k
+// fan although the code is never executed there: it pushes the kernel past 256 VGPRs and adds SGPR
+// spills in the hot loop.
 // The template argument EQ of the kernels carries the flag: EQ = model | (UE ? kEqUnitExp : 0).
 constexpr int kEqUnitExp = 4;
 template <bool UE, bool Y1>
@@ -136,7 +137,7 @@ RAYS_DEV double pow_u(double x, double y) {
   if (UE) return Y1 ? x : 1.0;
   if (y == 1.0) return x;
   if (y == 0.0) return 1.0;
-  return pow(x, y);
+  return libm::pow(x, y);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -295,7 +296,7 @@ RAYS_DEV int slab_fields(const DevParams& P, const double rvec[3], double bvec[3
       gradns[is][0] = P.n0s[is] * fp;
     }
   } else {  // Gaussian
-    const double g = exp(-3. * P.s_an1 * sq(x / P.s_rmin));
+    const double g = libm::exp(-3. * P.s_an1 * sq(x / P.s_rmin));
     const double gp = -6. * P.s_an1 * x / P.rmin2;
 #pragma unroll
     for (int is = 0; is < NS; is++) {
@@ -988,7 +989,7 @@ RAYS_DEV Cplx zfun_real_arg_spline(const DevParams& P, double z) {
   }
   Cplx r;
   r.re = re;
-  r.im = 1.7724538509055159 * exp(-(z * z));  // sqrt(pi)
+  r.im = 1.7724538509055159 * libm::exp(-(z * z));  // sqrt(pi)
   return r;
 }
 

@@ -641,7 +641,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
                 hnew = h;
                 if (p5eps < erk) {
                   const double temp2 = (double)(k + 1);
-                  const double r = pow(p5eps / erk, 1.0 / temp2);
+                  const double r = libm::pow(p5eps / erk, 1.0 / temp2);  // rays_libm.hpp: glibc's pow
                   hnew = absh * fmax(0.5, fmin((double)0.9f, r));
                   hnew = copysign(fmax(hnew, fouru * fabs(x)), h);
                 }

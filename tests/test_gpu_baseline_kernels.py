@@ -104,18 +104,12 @@ def test_sg_lane_refill_matches_oracle(which):
     out = hip.trace_host(p, R0, N0, ngpu=1)
     ora = oracle_lib.trace(p, r0, n0)
     assert (ora["npoints"] > 1).any()
-    bitwise = 0
     for b in range(0, 163840, nml_rays):
         m = min(nml_rays, 163840 - b)
         np.testing.assert_array_equal(out["npoints"][b:b + m], ora["npoints"][:m])
         np.testing.assert_array_equal(out["stop_code"][b:b + m], ora["stop_code"][:m])
-        d = np.abs(out["ray_vec"][b:b + m, :, :6] - ora["ray_vec"][:m, :, :6])
-        scale = np.abs(ora["ray_vec"][:m, :, :6]).max(axis=(1, 2), keepdims=True)
-        assert (d <= 1e-10 * scale).all()
-        bitwise += int(np.array_equal(out["ray_vec"][b:b + m], ora["ray_vec"][:m]))
-        # every tile is the same computation: the device result itself must not depend on where a ray ran
-        np.testing.assert_array_equal(out["ray_vec"][b:b + m], out["ray_vec"][:m])
-    print(f"{which}: {bitwise} of {163840 // nml_rays} tiles bit-identical to the oracle")
+        for k in ("ray_vec", "residual", "end_ray_vec", "end_residuals", "max_residuals"):
+            np.testing.assert_array_equal(out[k][b:b + m], ora[k][:m], err_msg=f"tile at ray {b}: {k}")
 
 
 def test_host_entry_with_several_slots_per_device():
@@ -154,8 +148,9 @@ def test_fused_scan_one_launch_matches_oracle():
             np.testing.assert_array_equal(getattr(r, k), ora[k], err_msg=f"ds={v}: {k}")
 
 
-# Fixtures whose ACCUMULATED trajectories differ from the reference's beyond 1e-10 on some rays (libm pow / exp of
-# ocml vs glibc, amplified along the ray by the finite-difference derivatives), plus the other libm users.
+# The libm users (profiles with exp / pow, the Z function, the SG step-size update) and the finite-difference dD
+# that amplifies an ulp by 1e8: with the device library's own exp / pow two of these missed the per-step bar
+# (2.7e-8, 2.7e-10); with rays_libm.hpp (glibc's algorithms) every restarted step is bit-identical.
 PER_STEP_CASES = ["gold_slab_shear_gauss_3spec_sg_num", "gold_axisym64_eqdsk_tspline_rk4_num",
                   "gold_solovev64_sg_num", "gold_solovev64_arcl_grad_sg", "gold_solovev64_damp_sg",
                   "gold_axisym64_eqdsk_damp_sg", "gold_solovev64_pow_rk4", "gold_solovev64_rk4_num"]
@@ -181,20 +176,31 @@ def test_per_step_parity_from_reference_points(name):
     v0, v1, s0 = np.concatenate(v0), np.concatenate(v1), np.concatenate(s0)
     got, resid, code = hip.ode_step(p, v0, s0)
     assert (code == 0).all(), f"{(code != 0).sum()} of {len(code)} restarted steps stopped: {np.unique(code)}"
-    worst = 0.0
-    for sl in (slice(0, 3), slice(3, 6)):
-        num = np.linalg.norm(got[:, sl] - v1[:, sl], axis=-1)
-        den = np.linalg.norm(v1[:, sl], axis=-1)
-        worst = max(worst, float((num / den).max()))
-    d7 = np.abs(got[:, 6] - v1[:, 6]) / np.maximum(np.abs(v1[:, 6]), 1e-300)
-    worst = max(worst, float(d7.max()))
-    nbit = int((got[:, :7] == v1[:, :7]).all(axis=1).sum())
-    print(f"{name}: {len(v0)} one-step restarts, {nbit} bit-identical, worst per-step rel err {worst:.3e}")
-    assert worst <= 1e-10
-    if p.nv > 7 and p.damping_model:
-        # absorbed-power row: single-precision temporaries in the reference (see tests/common.py), per step too
-        np.testing.assert_allclose(got[:, 7], v1[:, 7], rtol=1e-6, atol=1e-9)
-    g0 = 8 if p.damping_model else 7
-    if p.nv > g0:
-        scale = np.maximum(np.abs(v1[:, g0:]), np.abs(v1[:, g0:]).max(axis=0, keepdims=True) * 1e-3)
-        assert (np.abs(got[:, g0:] - v1[:, g0:]) <= 1e-10 * scale).all()
+    np.testing.assert_array_equal(got, v1)   # every restarted step lands on the reference's next point, bit for bit
+
+
+@pytest.mark.parametrize("cfg,stride,kernel", [
+    ("cfg3_solovev64k_sg_num.in", 128, "sg_trace_kernel<5, 2, 1, 7>"),
+    ("cfg5_axisym256k_sg_damp.in", 512, "sg_trace_kernel<6, 2, 0, 8>"),
+    ("cfg5b_axisym256k_rk4_damp.in", 512, "rk4_trace_kernel<6, 2, 0, 8>")])
+def test_baseline_config_at_full_size_sampled_against_oracle(cfg, stride, kernel):
+    """BASELINE configs 3 and 5 at their full sizes (65536 rays SG + finite-difference dD; 262144 rays eqdsk
+    splines + damping, SG and RK4): every `stride`-th ray of the device result against the oracle's trace of
+    just those rays, bit for bit, plus the size-independent properties."""
+    from rays_amd.trace import DeviceTrace
+    tab = None
+    if "axisym" in cfg:
+        g, _, _ = load_golden("gold_axisym64_eqdsk_damp_sg")
+        tab = {k[4:]: (float(g[k]) if g[k].ndim == 0 else g[k]) for k in g.files if k.startswith("axi_")}
+    p, r0, n0 = _fan(cfg, {}, tables=tab)
+    assert hip.kernel_name(p, len(r0)) == kernel
+    tr = DeviceTrace(p, r0, n0)
+    tr.launch()
+    a = tr.results()
+    sel = np.arange(0, len(r0), stride)
+    ora = oracle_lib.trace(p, r0[sel], n0[sel], nthreads=os.cpu_count() or 1)
+    for k in ARRAYS:
+        np.testing.assert_array_equal(getattr(a, k)[sel], ora[k], err_msg=k)
+    live = np.arange(p.nstep_max + 1)[None, :] < a.npoints[:, None]
+    assert not a.ray_vec[~live].any() and not a.residual[~live].any()
+    assert np.isfinite(a.ray_vec[live]).all()

@@ -9,9 +9,10 @@ from tests.common import GOLDEN_CASES, assert_matches_golden, load_golden
 
 pytestmark = pytest.mark.gpu
 
-# gold_solovev64_pow_rk4: profile exponents 1.5 / 2 -> the general kernels (ocml pow vs the
-# reference's glibc pow: within the 1e-10 bar, not necessarily bitwise); every other case has unit
-# exponents and runs the unit-exponent kernels
+# Every case is held to BIT equality with the reference: the kernels follow the reference's operation order
+# in IEEE binary64 without contraction, and exp / pow are glibc's algorithms (rays_amd/csrc/rays_libm.hpp), so
+# not even the libm users (gold_solovev64_pow_rk4, the Gaussian slab profile, the Z function, the
+# Shampine-Gordon step-size update) differ in the last bit.
 RK4_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_num", "gold_solovev64_pow_rk4",
              "gold_solovev_evanescent_rk4",
              "gold_solovev64_damp_rk4", "gold_axisym64_eqdsk_damp_rk4",
@@ -23,36 +24,21 @@ RK4_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_num"
 SG_CASES = ["gold_solovev64_sg_cold", "gold_solovev64_sg_num", "gold_solovev64_damp_sg", "gold_axisym64_eqdsk_damp_sg",
             "gold_solovev64_arcl_grad_sg", "gold_solovev64_slow_sg",
             "gold_slab_shear_gauss_3spec_sg_num"]
-# Gaussian density (libm exp in the profile) differentiated numerically: deriv_num's differences of D
-# over 1e-6 offsets amplify an ulp of exp (ocml here, glibc in the reference) by ~1e8 at every RHS,
-# so every ray drifts at the reference's own noise floor.  Counts and stop flags are exact; the
-# trajectories are held to 1e-6 (observed 1.2e-7).  The same kernel source on the host (glibc exp) is
-# bit-identical (tests/test_cpu_kernel_emul.py).
-LIBM_PROFILE_TOL = {"gold_slab_shear_gauss_3spec_sg_num": 1e-6,
-                    # parabolic density with exponents 1.5 / 2 (libm pow) under deriv_num, same mechanism
-                    "gold_axisym64_eqdsk_tspline_rk4_num": 1e-6}
-
 
 @pytest.mark.parametrize("name", RK4_CASES)
 def test_rk4_matches_reference_golden(name):
     g, nml, p = load_golden(name)
     out = hip.trace_host(p, g["rvec0"], g["rindex_vec0"], ngpu=1)
-    tol = LIBM_PROFILE_TOL.get(name, 1e-10)
-    worst = assert_matches_golden(out, g, p, rel_tol=tol, resid_atol=1e-12 if tol == 1e-10 else 1e-9)
-    keep = g["ray_vec"].shape[1]
-    print(f"{name}: worst rel err vs reference {worst:.3e}; ray_vec bitwise: "
-          f"{np.array_equal(out['ray_vec'][:, :keep], g['ray_vec'])}")
+    assert_matches_golden(out, g, p, exact=True)
 
 
 @pytest.mark.parametrize("name", SG_CASES)
 def test_sg_matches_reference_golden(name):
-    """Shampine-Gordon adaptive stepper (+ numerical dD): exact npoints / stop flags incl.
-    'equations stiff', 'ODE total error' and box exits; trajectories within 1e-10."""
+    """Shampine-Gordon adaptive stepper (+ numerical dD): npoints / stop flags incl. 'equations stiff',
+    'ODE total error' and box exits, trajectories, residuals and summaries bit-identical to the reference."""
     g, nml, p = load_golden(name)
     out = hip.trace_host(p, g["rvec0"], g["rindex_vec0"], ngpu=1)
-    tol = LIBM_PROFILE_TOL.get(name, 1e-10)
-    worst = assert_matches_golden(out, g, p, rel_tol=tol, resid_atol=1e-12 if tol == 1e-10 else 1e-9)
-    print(f"{name}: worst rel err vs reference {worst:.3e}")
+    assert_matches_golden(out, g, p, exact=True)
 
 
 @pytest.mark.parametrize("name", SG_CASES)
@@ -61,25 +47,8 @@ def test_sg_full_fan_matches_oracle(name):
     out = hip.trace_host(p, g["rvec0_full"], g["rindex_vec0_full"], ngpu=1)
     np.testing.assert_array_equal(out["npoints"], g["npoints_full"])
     ora = oracle_lib.trace(p, g["rvec0_full"], g["rindex_vec0_full"])
-    np.testing.assert_array_equal(out["stop_code"], ora["stop_code"])
-    rel = 0.0
-    per_ray = np.zeros(len(ora["npoints"]))
-    for sl in (slice(0, 3), slice(3, 6)):
-        num = np.linalg.norm(out["ray_vec"][..., sl] - ora["ray_vec"][..., sl], axis=-1)
-        den = np.maximum(np.linalg.norm(ora["ray_vec"][..., sl], axis=-1), 1e-300)
-        per_ray = np.maximum(per_ray, (num / den).max(axis=1))
-    nbit = int((np.abs(out["ray_vec"] - ora["ray_vec"]).max(axis=(1, 2)) == 0).sum())
-    print(f"{name}: {nbit}/{len(per_ray)} rays bitwise, worst accumulated rel err {per_ray.max():.3e}")
-    if name in LIBM_PROFILE_TOL:
-        assert per_ray.max() <= LIBM_PROFILE_TOL[name]
-    elif p.ray_deriv == 0:
-        assert per_ray.max() <= 1e-10
-    else:
-        # SG + finite-difference dD: the step-size update calls libm pow (ode_RAYS.f90:1222); a
-        # 1-ulp difference between ocml and glibc pow moves h by 1 ulp, and the finite-difference
-        # derivatives (noise floor ~1e-10) amplify that along a few rays.  Counts and
-        # stop flags stay exact; >= 90 % of rays stay within 1e-10, all within 1e-6.
-        assert (per_ray <= 1e-10).mean() >= 0.9 and per_ray.max() <= 1e-6
+    for k in ("stop_code", "npoints", "ray_vec", "residual", "end_ray_vec", "end_residuals", "max_residuals"):
+        np.testing.assert_array_equal(out[k], ora[k], err_msg=k)   # the whole fan, bit for bit
 
 
 @pytest.mark.parametrize("name", ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_pow_rk4",
@@ -93,15 +62,8 @@ def test_device_functions_match_reference_probes(name):
     dev = hip.probe(q, pr["v"][:, :7])
     for key in ("cold", "num", "dvds"):
         ref = pr[key][:, :7]
-        err = np.abs(dev[key] - ref) / np.maximum(np.abs(ref), 1e-300)
-        err = np.where(np.isnan(ref) & np.isnan(dev[key]), 0.0, err)
-        # finite-difference dD: differences of D at +-0.5e-6 relative offsets amplify an ulp of
-        # libm pow (ocml vs glibc, general-exponent profiles only) by ~1e8
-        tol = (1e-6 if name == "gold_solovev64_pow_rk4" else 1e-9) if key == "num" else 1e-12
-        assert np.nanmax(err) < tol, (key, np.nanmax(err))
-        print(name, key, "bitwise" if np.array_equal(dev[key], ref, equal_nan=True) else f"max rel {np.nanmax(err):.2e}")
-    both_nan = np.isnan(pr["resid"]) & np.isnan(dev["resid"])
-    assert (both_nan | (np.abs(dev["resid"] - pr["resid"]) <= 1e-12)).all()
+        np.testing.assert_array_equal(dev[key], ref, err_msg=key)   # NaN == NaN here
+    np.testing.assert_array_equal(dev["resid"], pr["resid"])
 
 
 def test_full_fan_matches_oracle():
@@ -133,11 +95,7 @@ def test_device_ray_init_matches_reference(name):
     fan, nray_max = fan_from_namelist(nml)
     r0, n0, w = hip.ray_init_host(p, fan, nray_max)
     np.testing.assert_array_equal(r0, g["rvec0_full"])
-    if name in LIBM_PROFILE_TOL and p.equilib_model == 2:
-        # the launch-point density is a libm pow (ocml here, glibc in the reference): n1 within an ulp or two
-        np.testing.assert_allclose(n0, g["rindex_vec0_full"], rtol=2e-15, atol=0)
-    else:
-        np.testing.assert_array_equal(n0, g["rindex_vec0_full"])
+    np.testing.assert_array_equal(n0, g["rindex_vec0_full"])
     tab = {k[4:]: (float(g[k]) if g[k].ndim == 0 else g[k]) for k in g.files if k.startswith("axi_")}
     _, _, w_host = initialize_ray_init(p, nml, tab or None)
     np.testing.assert_array_equal(w, w_host)
