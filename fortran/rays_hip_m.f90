@@ -99,12 +99,28 @@
        real(c_double) :: rindex_y0, delta_rindex_y0, rindex_z0, delta_rindex_z0
     end type rays_fan_t
 
+    ! device-resident result of rays_hip_trace_gather (rays_device_result_t of rays_hip.h)
+    type, bind(C) :: rays_device_result_t
+       integer(c_int32_t) :: device, nray
+       type(c_ptr) :: ray_vec, residual, npoints, stop_code, end_ray_vec, end_residuals, max_residuals
+    end type rays_device_result_t
+
+    integer(c_int), parameter :: RAYS_TRACE_NO_ZERO_FILL = 1
+    integer(c_int), parameter :: RAYS_DEP_PTOTAL_PSI = 0, RAYS_DEP_PTOTAL_RHO = 1, RAYS_DEP_PTOTAL_X = 2
+
     interface
 
        integer(c_int) function rays_hip_init(ngpu) bind(C, name='rays_hip_init')
           import :: c_int
           integer(c_int), value :: ngpu
        end function rays_hip_init
+
+       ! explicit slot -> device list for rays_hip_trace / rays_hip_trace_gather
+       integer(c_int) function rays_hip_init_devices(n, device_ids) bind(C, name='rays_hip_init_devices')
+          import :: c_int
+          integer(c_int), value :: n
+          integer(c_int), intent(in) :: device_ids(*)
+       end function rays_hip_init_devices
 
        integer(c_int) function rays_hip_finalize() bind(C, name='rays_hip_finalize')
           import :: c_int
@@ -153,6 +169,98 @@
           real(c_double), intent(out) :: elapsed_s
        end function rays_hip_trace
 
+       ! Multi-GPU trace whose result stays in device memory on the root device (RCCL gather of the blocks'
+       ! packed trajectories: SURVEY 8(e)); rays_hip_result_to_host copies it into ray_results_m's arrays,
+       ! rays_hip_deposition_device consumes it in place.
+       integer(c_int) function rays_hip_trace_gather(p, nray, rvec0, rindex_vec0, result) &
+                    & bind(C, name='rays_hip_trace_gather')
+          import :: c_int, c_double, rays_params_t, rays_device_result_t
+          type(rays_params_t), intent(in) :: p
+          integer(c_int), value :: nray
+          real(c_double), intent(in) :: rvec0(3,*), rindex_vec0(3,*)
+          type(rays_device_result_t), intent(out) :: result
+       end function rays_hip_trace_gather
+
+       integer(c_int) function rays_hip_result_to_host(p, result, ray_vec, residual, npoints, stop_code, &
+                    & end_ray_vec, end_residuals, max_residuals) bind(C, name='rays_hip_result_to_host')
+          import :: c_int, c_int32_t, c_double, rays_params_t, rays_device_result_t
+          type(rays_params_t), intent(in) :: p
+          type(rays_device_result_t), intent(in) :: result
+          real(c_double), intent(inout) :: ray_vec(*), residual(*)
+          integer(c_int32_t), intent(inout) :: npoints(*), stop_code(*)
+          real(c_double), intent(inout) :: end_ray_vec(*), end_residuals(*), max_residuals(*)
+       end function rays_hip_result_to_host
+
+       ! Device-pointer forms (type(c_ptr) = device memory on the current HIP device; hip_stream = a hipStream_t
+       ! or c_null_ptr): the trace, the fused `ds` scan (ray_scan.f90:33-49), one ode_solver step from arbitrary
+       ! states (ode_m.f90:218-254), the device ray launcher and the deposition profiles.
+       integer(c_int) function rays_hip_trace_device(p, nray, d_rvec0, d_rindex_vec0, d_ray_vec, d_residual, &
+                    & d_npoints, d_stop_code, d_end_ray_vec, d_end_residuals, d_max_residuals, hip_stream, flags) &
+                    & bind(C, name='rays_hip_trace_device')
+          import :: c_int, c_ptr, rays_params_t
+          type(rays_params_t), intent(in) :: p
+          integer(c_int), value :: nray
+          type(c_ptr), value :: d_rvec0, d_rindex_vec0, d_ray_vec, d_residual, d_npoints, d_stop_code
+          type(c_ptr), value :: d_end_ray_vec, d_end_residuals, d_max_residuals, hip_stream
+          integer(c_int), value :: flags
+       end function rays_hip_trace_device
+
+       integer(c_int) function rays_hip_scan_device(p, n_runs, d_ds_values, nray, d_rvec0, d_rindex_vec0, &
+                    & d_ray_vec, d_residual, d_npoints, d_stop_code, d_end_ray_vec, d_end_residuals, &
+                    & d_max_residuals, hip_stream, flags) bind(C, name='rays_hip_scan_device')
+          import :: c_int, c_ptr, rays_params_t
+          type(rays_params_t), intent(in) :: p
+          integer(c_int), value :: n_runs, nray
+          type(c_ptr), value :: d_ds_values, d_rvec0, d_rindex_vec0, d_ray_vec, d_residual, d_npoints, d_stop_code
+          type(c_ptr), value :: d_end_ray_vec, d_end_residuals, d_max_residuals, hip_stream
+          integer(c_int), value :: flags
+       end function rays_hip_scan_device
+
+       integer(c_int) function rays_hip_ode_step_device(p, n, d_v0, d_s0, d_v1, d_resid, d_stop_code, hip_stream) &
+                    & bind(C, name='rays_hip_ode_step_device')
+          import :: c_int, c_ptr, rays_params_t
+          type(rays_params_t), intent(in) :: p
+          integer(c_int), value :: n
+          type(c_ptr), value :: d_v0, d_s0, d_v1, d_resid, d_stop_code, hip_stream
+       end function rays_hip_ode_step_device
+
+       integer(c_int) function rays_hip_ray_init_device(p, fan, nray_max, d_rvec0, d_rindex_vec0, nray, hip_stream) &
+                    & bind(C, name='rays_hip_ray_init_device')
+          import :: c_int, c_int32_t, c_ptr, rays_params_t, rays_fan_t
+          type(rays_params_t), intent(in) :: p
+          type(rays_fan_t), intent(in) :: fan
+          integer(c_int), value :: nray_max
+          type(c_ptr), value :: d_rvec0, d_rindex_vec0, hip_stream
+          integer(c_int32_t), intent(out) :: nray
+       end function rays_hip_ray_init_device
+
+       ! Deposition profiles (post_process_lib/deposition_profiles_m.f90:228-292).  rho(psiN) spline for 'Ptotal_rho':
+       integer(c_int) function rays_hip_set_rho_table(grid, fspl, n) bind(C, name='rays_hip_set_rho_table')
+          import :: c_int, c_double
+          real(c_double), intent(in) :: grid(*), fspl(4,*)
+          integer(c_int), value :: n
+       end function rays_hip_set_rho_table
+
+       integer(c_int) function rays_hip_deposition_device(p, which, n_bins, nray, d_ray_vec, d_npoints, &
+                    & d_initial_ray_power, d_work, d_profile_in, d_profile_out, hip_stream) &
+                    & bind(C, name='rays_hip_deposition_device')
+          import :: c_int, c_ptr, rays_params_t
+          type(rays_params_t), intent(in) :: p
+          integer(c_int), value :: which, n_bins, nray
+          type(c_ptr), value :: d_ray_vec, d_npoints, d_initial_ray_power, d_work, d_profile_in, d_profile_out, hip_stream
+       end function rays_hip_deposition_device
+
+       ! host arrays in the reference's layouts: ray_vec(nv, nstep_max+1, nray), work(n_bins, nray), profile(n_bins)
+       integer(c_int) function rays_hip_deposition(p, which, n_bins, nray, ray_vec, npoints, initial_ray_power, &
+                    & work, profile) bind(C, name='rays_hip_deposition')
+          import :: c_int, c_int32_t, c_double, rays_params_t
+          type(rays_params_t), intent(in) :: p
+          integer(c_int), value :: which, n_bins, nray
+          real(c_double), intent(in) :: ray_vec(*), initial_ray_power(*)
+          integer(c_int32_t), intent(in) :: npoints(*)
+          real(c_double), intent(inout) :: work(*), profile(*)
+       end function rays_hip_deposition
+
        ! Replaces the serial launch loops of ray_init_m's launchers (solovev_ray_init_nphi_ntheta_m.f90:
        ! 60-198 etc.): fills rvec0(3,nray_max), rindex_vec0(3,nray_max), ray_pwr_wt(nray_max), nray.
        integer(c_int) function rays_hip_ray_init(p, fan, nray_max, rvec0, rindex_vec0, ray_pwr_wt, nray) &
@@ -168,6 +276,32 @@
     end interface
 
  contains
+
+    integer(c_int32_t) function wave_mode_code(wave_mode)
+    ! rf_m's wave_mode string -> RAYS_WAVE_* (dispersion_solvers_m.f90:86-101 stops on anything else)
+       character(len=*), intent(in) :: wave_mode
+       select case (trim(wave_mode))
+          case ('plus');  wave_mode_code = RAYS_WAVE_PLUS
+          case ('minus'); wave_mode_code = RAYS_WAVE_MINUS
+          case ('fast');  wave_mode_code = RAYS_WAVE_FAST
+          case ('slow');  wave_mode_code = RAYS_WAVE_SLOW
+          case default
+             write(0,*) 'solve_disp: improper wave_mode = ', trim(wave_mode); stop 1
+       end select
+    end function wave_mode_code
+
+    subroutine clear_fan(fan)
+       type(rays_fan_t), intent(out) :: fan
+       fan%model = 0 ; fan%wave_mode = 0 ; fan%k0_sign = 1
+       fan%n_r_launch = 0 ; fan%n_theta_launch = 0 ; fan%n_rindex_theta = 0 ; fan%n_rindex_phi = 0
+       fan%r_launch0 = 0. ; fan%dr_launch = 0. ; fan%theta_launch0 = 0. ; fan%dtheta_launch = 0. ; fan%z_launch0 = 0.
+       fan%rindex_theta0 = 0. ; fan%delta_rindex_theta = 0. ; fan%rindex_phi0 = 0. ; fan%delta_rindex_phi = 0.
+       fan%n_x_launch = 0 ; fan%n_y_launch = 0 ; fan%n_z_launch = 0 ; fan%n_ky_launch = 0
+       fan%n_kz_launch = 0 ; fan%pad_ = 0
+       fan%x_launch0 = 0. ; fan%dx_launch = 0. ; fan%y_launch0 = 0. ; fan%dy_launch = 0.
+       fan%slab_z_launch0 = 0. ; fan%rindex_y0 = 0. ; fan%delta_rindex_y0 = 0.
+       fan%rindex_z0 = 0. ; fan%delta_rindex_z0 = 0.
+    end subroutine clear_fan
 
     function stop_flag_string(stop_code) result(flag)
     ! integer stop code -> the reference's ode_stop_flag text (e.g. ' nstep > nstep_max')

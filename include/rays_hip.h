@@ -270,6 +270,32 @@ const char* rays_hip_kernel_name(const rays_params_t* p);
 /* Same for a fan of nray rays: large fans may get a differently tuned build of the kernel. */
 const char* rays_hip_kernel_name_for(const rays_params_t* p, int nray);
 
+/* ---- multi-GPU trace with a device-resident result: the final trajectory gather over RCCL -------
+ * (north_star: "RCCL over xGMI used only for the final trajectory gather".)
+ * Shards the rays in contiguous blocks over the devices chosen by rays_hip_init[_devices] (distinct devices;
+ * one host thread per device, like rays_hip_trace), traces every block on its device, then gathers the blocks'
+ * PACKED trajectories and per-ray summaries on the root (= the first device of the list) with one grouped batch of
+ * ncclSend/ncclRecv -- every peer uses its own xGMI link to the root -- and unpacks them there into the padded
+ * reference layout.  The result stays in device memory on the root, owned by the library and valid until the
+ * next rays_hip_trace_gather call or rays_hip_finalize; follow-on device work (rays_hip_deposition_device) can
+ * consume it in place, rays_hip_result_to_host copies it out.  librccl.so is loaded on the first call with more
+ * than one device.  rvec0 / rindex_vec0 are host arrays ([nray][3]). */
+typedef struct rays_device_result {
+  int32_t device, nray;
+  double* ray_vec;       /* [nray][nstep_max+1][nv], zero past npoints */
+  double* residual;      /* [nray][nstep_max+1] */
+  int32_t* npoints;      /* [nray] */
+  int32_t* stop_code;    /* [nray] */
+  double* end_ray_vec;   /* [nray][nv] */
+  double* end_residuals; /* [nray] */
+  double* max_residuals; /* [nray] */
+} rays_device_result_t;
+int rays_hip_trace_gather(const rays_params_t* p, int nray, const double* rvec0, const double* rindex_vec0,
+                          rays_device_result_t* result);
+int rays_hip_result_to_host(const rays_params_t* p, const rays_device_result_t* result, double* ray_vec,
+                            double* residual, int32_t* npoints, int32_t* stop_code, double* end_ray_vec,
+                            double* end_residuals, double* max_residuals);
+
 /* ---- multi-GPU trajectory exchange helpers ---------------------------------
  * The padded reference layout is mostly zeros (a ray uses npoints of nstep_max+1 slots).  Before
  * the RCCL gather a rank packs its slab to packed_vec[sum(npoints)][nv], packed_res[sum(npoints)]
@@ -348,6 +374,12 @@ int rays_hip_deposition_device(const rays_params_t* p, int which, int n_bins, in
                                const double* d_ray_vec, const int32_t* d_npoints,
                                const double* d_initial_ray_power, double* d_work,
                                const double* d_profile_in, double* d_profile_out, void* hip_stream);
+
+/* Host-pointer form: ray_vec[nray][nstep_max+1][nv], npoints[nray], initial_ray_power[nray] are the
+ * ray_results_m arrays; work[nray][n_bins] (= the reference's work(n_bins, nray), may be NULL) and
+ * profile[n_bins] are filled.  Only points 1..maxval(npoints) of each ray cross PCIe. */
+int rays_hip_deposition(const rays_params_t* p, int which, int n_bins, int nray, const double* ray_vec,
+                        const int32_t* npoints, const double* initial_ray_power, double* work, double* profile);
 
 /* Diagnostic entry used by the parity tests: evaluates equilibrium + deriv_cold + deriv_num +
  * eqn_ray + check_save at n states on the current device (host pointers; nv must be 7, nspec 1|2).

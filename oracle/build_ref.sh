@@ -4,8 +4,9 @@
 #
 #   oracle/_ref/rays_ref_dump   reference initialize + trace_rays + raw-binary dump (CPU)
 #   oracle/_ref/rays_hip_dropin reference host (initialize/ray_results/...) with trace_rays
-#                               REPLACED by fortran/trace_rays_hip.f90 and the Solovev ray launcher
-#                               by fortran/solovev_ray_init_hip.f90 -> C-ABI
+#                               REPLACED by fortran/trace_rays_hip.f90, the three ray launchers by
+#                               fortran/{solovev,simple_slab,axisym_toroid}_ray_init_hip.f90 and the
+#                               deposition binning by fortran/deposition_profiles_hip.f90 -> C-ABI
 #
 # Nothing from /root/reference is kept: sources are streamed through `sed` into a scratch
 # directory that is deleted before the script exits (objects, .mod files too); only the two
@@ -106,7 +107,7 @@ LIBOBJS=$(for m in $MODS $EXTS; do echo "$m.o"; done)
 
 # ---- (1) reference CPU path + dump driver ---------------------------------------------------
 $FC $FFLAGS -c ray_tracing_ref.f90 -o ray_tracing_ref.o
-$FC $FFLAGS -c "$HERE/ref_dump_driver.f90" -o ref_dump_driver.o
+$FC $FFLAGS -cpp -c "$HERE/ref_dump_driver.f90" -o ref_dump_driver.o
 $FC $FFLAGS -o "$OUT/rays_ref_dump" ref_dump_driver.o ray_tracing_ref.o $LIBOBJS
 
 # ---- (2) drop-in: same host objects, trace_rays replaced by the HIP shim --------------------
@@ -117,13 +118,22 @@ if [ -f "$LIBHIP" ]; then
   $FC $FFLAGS -c "$ROOT/fortran/trace_rays_hip.f90" -o trace_rays_hip.o
   # the Solovev ray launcher replaced too: our module takes the place of the
   # reference's solovev_ray_init_nphi_ntheta_m, and ray_init_m is recompiled against it
-  $FC $FFLAGS -c "$ROOT/fortran/solovev_ray_init_hip.f90" -o solovev_ray_init_hip.o
-  $FC $FFLAGS -c ray_init_m.f90 -o ray_init_m_dropin.o
+  # (its own object directory: the replacement modules write .mod files of the same names as the reference's)
+  mkdir -p dropin && cp *.mod dropin/ 2>/dev/null || true
+  DF="$FFLAGS -module-dir dropin -Idropin"
+  $FC $DF -c "$ROOT/fortran/solovev_ray_init_hip.f90" -o solovev_ray_init_hip.o
+  $FC $DF -c "$ROOT/fortran/simple_slab_ray_init_hip.f90" -o simple_slab_ray_init_hip.o
+  $FC $DF -c "$ROOT/fortran/axisym_toroid_ray_init_hip.f90" -o axisym_toroid_ray_init_hip.o
+  $FC $DF -c ray_init_m.f90 -o ray_init_m_dropin.o
+  $FC $DF -c "$ROOT/fortran/deposition_profiles_hip.f90" -o deposition_profiles_hip.o
   DROPOBJS=$(for m in $MODS $EXTS; do
       case "$m" in solovev_ray_init_nphi_ntheta_m) echo solovev_ray_init_hip.o;;
+                   simple_slab_ray_init_m) echo simple_slab_ray_init_hip.o;;
+                   axisym_toroid_ray_init_R_Z_nphi_ntheta_m) echo axisym_toroid_ray_init_hip.o;;
                    ray_init_m) echo ray_init_m_dropin.o;;
                    *) echo "$m.o";; esac; done)
-  $FC $FFLAGS -c "$HERE/ref_dump_driver.f90" -o ref_dump_driver2.o
+  DROPOBJS="$DROPOBJS deposition_profiles_hip.o"
+  $FC $DF -cpp -DRAYS_DROPIN -c "$HERE/ref_dump_driver.f90" -o ref_dump_driver2.o
   $FC $FFLAGS -o "$OUT/rays_hip_dropin" ref_dump_driver2.o trace_rays_hip.o rays_hip_state_m.o rays_hip_m.o $DROPOBJS \
      -L"$ROOT/rays_amd/lib" -lrays_hip -Wl,-rpath,'$ORIGIN/../../rays_amd/lib'
 else

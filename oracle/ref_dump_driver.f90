@@ -37,6 +37,11 @@ program ref_dump_driver
     use density_spline_interp_m, only : ne_profile_N
     use temperature_spline_interp_m, only : Te_profileN, Ti_profileN
     use omp_lib
+#ifdef RAYS_DROPIN
+    use, intrinsic :: iso_c_binding
+    use rays_hip_m, only : rays_hip_set_rho_table
+    use deposition_profiles_hip_m, only : deposition_profile_hip
+#endif
     implicit none
 
     logical :: read_input = .true.
@@ -48,6 +53,9 @@ program ref_dump_driver
     type(eq_point) :: eq
     type(ode_stop) :: rs
     integer(kind=8) :: total_steps
+#ifdef RAYS_DROPIN
+    real(kind=rkind), allocatable :: hwork(:,:), hprofile(:,:), hq(:)
+#endif
 
     interface
        subroutine deriv_cold(eq, nvec, dddx, dddk, dddw)
@@ -156,6 +164,23 @@ program ref_dump_driver
        else
           write(u2) 0
        end if
+#ifdef RAYS_DROPIN
+       ! drop-in binary: the profiles come from the GPU (fortran/deposition_profiles_hip.f90), same record layout
+       if (trim(equilib_model) == 'axisym_toroid') then
+          if (rays_hip_set_rho_table(rho_profile%x_grid, rho_profile%fspl, int(rho_profile%nx, c_int)) /= 0) stop 1
+       end if
+       allocate(hwork(profiles_1D(1)%n_bins, nray), hprofile(profiles_1D(1)%n_bins, n_profiles), hq(n_profiles))
+       do ip = 1, n_profiles
+          call deposition_profile_hip(trim(profiles_1D(ip)%profile_name), profiles_1D(ip)%n_bins, hwork, &
+               & hprofile(:, ip), hq(ip))
+          write(u2) profiles_1D(ip)%profile_name, profiles_1D(ip)%grid_min, profiles_1D(ip)%grid_max
+          write(u2) hwork
+       end do
+       do ip = 1, n_profiles
+          write(u2) hprofile(:, ip), hq(ip)
+       end do
+       close(u2)
+#else
        do ip = 1, n_profiles          ! per-ray binned arrays, as calculate_deposition_profiles fills them
           do iray = 1, nray
              call bin_a_ray(profiles_1D(ip), iray)
@@ -168,6 +193,7 @@ program ref_dump_driver
           write(u2) profiles_1D(ip)%profile, profiles_1D(ip)%Q_sum
        end do
        close(u2)
+#endif
     end if
 
     call get_environment_variable('RAYS_DUMP_AXISYM', sval, status=stat)

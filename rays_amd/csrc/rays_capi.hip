@@ -4,6 +4,7 @@
 // No oracle, no CPU fallback: every entry point either runs the HIP kernels or fails with an
 // error message.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -200,6 +201,8 @@ int get_axisym_device(rays::DevParams* D) {
   D->a_ne_grid = b + g_axi.off[5]; D->a_ne_fspl = b + g_axi.off[6];
   D->a_te_grid = b + g_axi.off[7]; D->a_te_fspl = b + g_axi.off[8];
   D->a_ti_grid = b + g_axi.off[9]; D->a_ti_fspl = b + g_axi.off[10];
+  D->a_tab1d_doubles = (int)(g_axi.blob.size() - g_axi.off[3]);  // rb .. ti: contiguous at the end of the blob
+  D->a_lds_tab = 0;
   return 0;
 }
 
@@ -240,6 +243,32 @@ int get_counter(unsigned int** out, int* slot_out) {
   }
   return 0;
 }
+// Workspace of the SG kernels' upper storage tiers (TraceArgs::sg_far), one per (device, stream): launches on a
+// stream run one after another, so they may share it; grown on demand, released by rays_hip_finalize.
+struct SgWorkspace {
+  double* ptr = nullptr;
+  size_t bytes = 0;
+};
+std::map<std::pair<int, hipStream_t>, SgWorkspace> g_sg_ws;
+int get_sg_workspace(hipStream_t stream, size_t bytes, double** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mu);
+  SgWorkspace& w = g_sg_ws[std::make_pair(dev, stream)];
+  if (w.bytes < bytes) {
+    if (w.ptr) {
+      HIP_TRY(hipStreamSynchronize(stream));  // an earlier launch on this stream may still use the old block
+      (void)hipFree(w.ptr);
+    }
+    w.ptr = nullptr;
+    w.bytes = 0;
+    HIP_TRY(hipMalloc(&w.ptr, bytes));
+    w.bytes = bytes;
+  }
+  *out = w.ptr;
+  return 0;
+}
+
 int counter_launched(int slot, hipStream_t stream) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
@@ -346,7 +375,9 @@ int rays_hip_init_devices(int n, const int* device_ids) {
 }
 
 static void release_cached_device_blocks();
+static void rccl_close_all();
 int rays_hip_finalize(void) {
+  rccl_close_all();
   std::lock_guard<std::mutex> lk(g_mu);
   for (int d = 0; d < 16; d++)
     if (g_ws[d].counters) {
@@ -361,6 +392,13 @@ int rays_hip_finalize(void) {
       }
       g_ws[d].next = 0;
     }
+  for (auto& kv : g_sg_ws)
+    if (kv.second.ptr) {
+      (void)hipSetDevice(kv.first.first);
+      (void)hipDeviceSynchronize();
+      (void)hipFree(kv.second.ptr);
+    }
+  g_sg_ws.clear();
   release_cached_device_blocks();
   g_devices.clear();
   return 0;
@@ -464,6 +502,21 @@ int launch_trace(const rays_params_t* p, int nray, const double* d_rvec0, const 
   A.s0 = extra.s0;
   A.ds_run = extra.ds_run;
   A.rays_per_run = extra.rays_per_run;
+  A.sg_far = nullptr;
+  A.sg_far_lanes = 0;
+  const rays::KernelEntry* kernel = find_kernel(*p, nray);
+  if (kernel->sg_far_per_lane > 0) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    // the SG kernels fill the CU's LDS with one workgroup, so at most one 256-lane block per CU is resident
+    const long long resident = (long long)rays::device_cu_count(dev) * rays::kBlock;
+    const long long want = ((long long)nray + rays::kBlock - 1) / rays::kBlock * rays::kBlock;
+    A.sg_far_lanes = want < resident ? want : resident;
+    double* ws = nullptr;
+    rc = get_sg_workspace(stream, sizeof(double) * (size_t)kernel->sg_far_per_lane * (size_t)A.sg_far_lanes, &ws);
+    if (rc) return rc;
+    A.sg_far = ws;
+  }
   rays::DevParams D = make_dev_params(*p);
   if (p->damping_model == RAYS_DAMP_FUND_ECH) {
     const double* zf = nullptr;
@@ -486,7 +539,7 @@ int launch_trace(const rays_params_t* p, int nray, const double* d_rvec0, const 
     if (need_ne || need_t) return fail("axisym_toroid: spline profile model selected but its table was not set");
   }
   int grid = 0;
-  hipError_t e = find_kernel(*p, nray)->launch(D, A, stream, &grid);
+  hipError_t e = kernel->launch(D, A, stream, &grid);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
   return counter_launched(counter_slot, stream);
 }
@@ -600,9 +653,9 @@ struct DeviceBlockCache {
     idle.clear();
   }
 };
-static DeviceBlockCache g_blocks[16];
+static DeviceBlockCache g_blocks[17];  // slots 0..15: the device list; 16: the gathered result (rays_gather.inc)
 static hipError_t cached_malloc(int slot, void** out, size_t bytes) {
-  if (slot < 0 || slot >= 16) return hipMalloc(out, bytes);
+  if (slot < 0 || slot >= 17) return hipMalloc(out, bytes);
   DeviceBlockCache& c = g_blocks[slot];
   std::lock_guard<std::mutex> lk(c.mu);
   size_t best = c.idle.size();
@@ -626,7 +679,7 @@ static hipError_t cached_malloc(int slot, void** out, size_t bytes) {
   return e;
 }
 static hipError_t cached_stream(int slot, hipStream_t* out, bool* owned) {
-  *owned = slot < 0 || slot >= 16;
+  *owned = slot < 0 || slot >= 17;
   if (*owned) return hipStreamCreate(out);
   DeviceBlockCache& c = g_blocks[slot];
   std::lock_guard<std::mutex> lk(c.mu);
@@ -639,7 +692,7 @@ static hipError_t cached_stream(int slot, hipStream_t* out, bool* owned) {
 }
 static void cached_free(int slot, void* ptr) {
   if (!ptr) return;
-  if (slot < 0 || slot >= 16) { (void)hipFree(ptr); return; }
+  if (slot < 0 || slot >= 17) { (void)hipFree(ptr); return; }
   DeviceBlockCache& c = g_blocks[slot];
   std::lock_guard<std::mutex> lk(c.mu);
   auto it = c.live.find(ptr);
@@ -649,7 +702,7 @@ static void cached_free(int slot, void* ptr) {
 }
 
 static void release_cached_device_blocks() {
-  for (int d = 0; d < 16; d++) {
+  for (int d = 0; d < 17; d++) {
     DeviceBlockCache& c = g_blocks[d];
     std::lock_guard<std::mutex> lk(c.mu);
     if (c.idle.empty() && !c.stream) continue;
@@ -1014,6 +1067,57 @@ int rays_hip_deposition_device(const rays_params_t* p, int which, int n_bins, in
   return 0;
 }
 
+// Host-pointer form of the deposition profiles: what a Fortran post-processor holding the ray_results_m arrays
+// calls instead of calculate_deposition_profiles (deposition_profiles_m.f90:228-260).  Only points 1..maxval(npoints)
+// of every ray cross PCIe (a strided copy); work comes back in the reference's work(n_bins, nray) layout.
+int rays_hip_deposition(const rays_params_t* p, int which, int n_bins, int nray, const double* ray_vec,
+                        const int32_t* npoints, const double* initial_ray_power, double* work, double* profile) {
+  int rc = rays_hip_check_params(p);
+  if (rc) return rc;
+  if (n_bins < 1 || nray < 0) return fail("rays_hip_deposition: bad n_bins / nray");
+  if (nray == 0) {
+    if (profile) std::memset(profile, 0, sizeof(double) * (size_t)n_bins);
+    return 0;
+  }
+  if (!ray_vec || !npoints || !initial_ray_power || !profile) return fail("rays_hip_deposition: null array argument");
+  const size_t nv = (size_t)p->nv, npt = (size_t)p->nstep_max + 1;
+  int maxnp = 1;
+  for (int i = 0; i < nray; i++) maxnp = std::max(maxnp, (int)npoints[i]);
+  if ((size_t)maxnp > npt) return fail("rays_hip_deposition: npoints exceeds nstep_max + 1");
+  rays_params_t q = *p;
+  q.nstep_max = maxnp - 1;  // the device copy holds maxnp points per ray
+  double *d_rv = nullptr, *d_pw = nullptr, *d_work = nullptr, *d_prof = nullptr;
+  int32_t* d_np = nullptr;
+  auto release = [&]() { (void)hipFree(d_rv); (void)hipFree(d_pw); (void)hipFree(d_work); (void)hipFree(d_prof); (void)hipFree(d_np); };
+#define DEP_TRY(call)                                                \
+  do {                                                               \
+    hipError_t e_ = (call);                                          \
+    if (e_ != hipSuccess) { release(); return hip_fail(e_, #call); } \
+  } while (0)
+  DEP_TRY(hipMalloc(&d_rv, sizeof(double) * nv * (size_t)maxnp * (size_t)nray));
+  DEP_TRY(hipMalloc(&d_pw, sizeof(double) * (size_t)nray));
+  DEP_TRY(hipMalloc(&d_work, sizeof(double) * (size_t)n_bins * (size_t)nray));
+  DEP_TRY(hipMalloc(&d_prof, sizeof(double) * (size_t)n_bins));
+  DEP_TRY(hipMalloc(&d_np, sizeof(int32_t) * (size_t)nray));
+  DEP_TRY(hipMemcpy2D(d_rv, sizeof(double) * nv * (size_t)maxnp, ray_vec, sizeof(double) * nv * npt,
+                      sizeof(double) * nv * (size_t)maxnp, (size_t)nray, hipMemcpyHostToDevice));
+  DEP_TRY(hipMemcpy(d_pw, initial_ray_power, sizeof(double) * (size_t)nray, hipMemcpyHostToDevice));
+  DEP_TRY(hipMemcpy(d_np, npoints, sizeof(int32_t) * (size_t)nray, hipMemcpyHostToDevice));
+  rc = rays_hip_deposition_device(&q, which, n_bins, nray, d_rv, d_np, d_pw, d_work, nullptr, d_prof, nullptr);
+  if (rc) { release(); return rc; }
+  DEP_TRY(hipDeviceSynchronize());
+  DEP_TRY(hipMemcpy(profile, d_prof, sizeof(double) * (size_t)n_bins, hipMemcpyDeviceToHost));
+  if (work) {  // device: [n_bins][nray]  ->  reference work(n_bins, nray) = C [nray][n_bins]
+    std::vector<double> w((size_t)n_bins * (size_t)nray);
+    DEP_TRY(hipMemcpy(w.data(), d_work, sizeof(double) * w.size(), hipMemcpyDeviceToHost));
+    for (int r = 0; r < nray; r++)
+      for (int b = 0; b < n_bins; b++) work[(size_t)r * n_bins + b] = w[(size_t)b * nray + r];
+  }
+#undef DEP_TRY
+  release();
+  return 0;
+}
+
 int rays_hip_sizeof_fan(void) { return (int)sizeof(rays_fan_t); }
 
 #include "rays_fan_setup.inc"
@@ -1167,3 +1271,6 @@ int rays_hip_probe(const rays_params_t* p, int n, const double* v, double* cold7
 }
 
 }  // extern "C"
+
+#include "rays_gather.inc"
+static void rccl_close_all() { rccl_close(); }

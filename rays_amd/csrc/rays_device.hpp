@@ -46,6 +46,12 @@ struct DevParams {
   double a_at1[RAYS_NS0], a_at2[RAYS_NS0];
   const double *a_r_grid, *a_z_grid, *a_psi_fspl, *a_rb_grid, *a_rb_fspl, *a_ne_grid, *a_ne_fspl,
       *a_te_grid, *a_te_fspl, *a_ti_grid, *a_ti_fspl;  // device pointers (L2-resident tables)
+  // The 1-D tables (rb .. ti) are one contiguous block of a_tab1d_doubles doubles starting at a_rb_grid.  A
+  // kernel with LDS to spare copies it there at its start and sets a_lds_tab to the copy's LDS byte address
+  // (0 = not staged): the profile lookups n(psi), T(psi), RBphi(R) then cost an LDS access instead of the second
+  // of two dependent trips to L2 per evaluation of the equilibrium.
+  int a_tab1d_doubles;
+  unsigned a_lds_tab;
   double ds, s_max, omgrf, k0, clight, eps0, resid_limit;
   double omgrf2;               // omgrf**2                      equilibrium_m.f90:264
   double two_over_k0;          // 2./k0                         deriv_cold.f90:51
@@ -447,7 +453,13 @@ RAYS_DEV int solovev_fields(const DevParams& P, const double rvec[3], double bve
 // memory: 16 doubles per bicubic cell (128 B = one cache line), 4 per cubic cell; neighbouring rays
 // hit the same or adjacent cells, so they stay L2-resident (65x65 cells = 540 KB).
 // ---------------------------------------------------------------------------------------------
-RAYS_DEV int spl_cell(const double* __restrict__ x, int nx, double xget, double& dx) {
+#ifdef RAYS_HOST_EMUL
+typedef const double* eq_lds_ptr;
+#else
+typedef const __attribute__((address_space(3))) double* eq_lds_ptr;
+#endif
+template <class PTR>
+RAYS_DEV int spl_cell(PTR x, int nx, double xget, double& dx) {
   const double x1 = x[0], xn = x[nx - 1];
   double z = xget;
   if (z < x1) z = x1;
@@ -463,11 +475,11 @@ RAYS_DEV int spl_cell(const double* __restrict__ x, int nx, double xget, double&
   return i;
 }
 
-RAYS_DEV void spl1_fp(const double* __restrict__ grid, const double* __restrict__ fspl, int n, double x,
-                      double& f, double& fp) {
+template <class PTR>
+RAYS_DEV void spl1_fp(PTR grid, PTR fspl, int n, double x, double& f, double& fp) {
   double dx;
   const int i = spl_cell(grid, n, x, dx);
-  const double* c = fspl + 4 * (long long)(i - 1);
+  const PTR c = fspl + 4 * (i - 1);
   const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
   f = c0 + dx * (c1 + dx * (c2 + dx * c3));
   fp = c1 + dx * (2.0 * c2 + dx * 3.0 * c3);
@@ -476,8 +488,8 @@ RAYS_DEV void spl1_fp(const double* __restrict__ grid, const double* __restrict_
 // eval_2D_fpp: f, fx, fy, fxx, fxy, fyy (quick_cube_splines_m.f90:305-332, bcspevfn ict = 1,1,1,1,1,1)
 RAYS_DEV void spl2_fpp(const DevParams& P, double x, double y, double out[6]) {
   double dx, dy;
-  const int i = spl_cell(P.a_r_grid, P.a_nr, x, dx);
-  const int j = spl_cell(P.a_z_grid, P.a_nz, y, dy);
+  const int i = spl_cell<const double*>(P.a_r_grid, P.a_nr, x, dx);
+  const int j = spl_cell<const double*>(P.a_z_grid, P.a_nz, y, dy);
   const double* c = P.a_psi_fspl + 16 * ((long long)(i - 1) + (long long)P.a_nr * (long long)(j - 1));
   double F[4][4];  // F[a-1][b-1] = f(a,b,i,j)
 #pragma unroll
@@ -505,6 +517,19 @@ RAYS_DEV void spl2_fpp(const DevParams& P, double x, double y, double out[6]) {
            1.5 * dx * (F[3][1] + dy * (2.0 * F[3][2] + dy * 3.0 * F[3][3])));  // fxy
 }
 
+// 1-D table lookup through the staged LDS copy when there is one (DevParams::a_lds_tab), else through L2
+RAYS_DEV void spl1_tab(const DevParams& P, const double* grid, const double* fspl, int n, double x, double& f,
+                       double& fp) {
+#ifndef RAYS_HOST_EMUL
+  if (P.a_lds_tab) {  // wave-uniform
+    const eq_lds_ptr base = (eq_lds_ptr)(unsigned long long)P.a_lds_tab;
+    spl1_fp<eq_lds_ptr>(base + (grid - P.a_rb_grid), base + (fspl - P.a_rb_grid), n, x, f, fp);
+    return;
+  }
+#endif
+  spl1_fp<const double*>(grid, fspl, n, x, f, fp);
+}
+
 // axisym_toroid_eq + eqdsk_magnetics_spline_interp
 //   axisym_toroid_eq_m.f90:215-362, eqdsk_magnetics_spline_interp_m.f90:206-282,
 //   density_spline_interp_m.f90:109-130, temperature_spline_interp_m.f90
@@ -522,7 +547,7 @@ RAYS_DEV int axisym_fields(const DevParams& P, const double rvec[3], double bvec
   double f6[6], RBphi, RBphiR;
   spl2_fpp(P, r, z, f6);
   const double psi = f6[0], PsiR = f6[1], PsiZ = f6[2], PsiRR = f6[3], PsiRZ = f6[4], PsiZZ = f6[5];
-  spl1_fp(P.a_rb_grid, P.a_rb_fspl, P.a_n_rb, r, RBphi, RBphiR);
+  spl1_tab(P, P.a_rb_grid, P.a_rb_fspl, P.a_n_rb, r, RBphi, RBphiR);
   const Recip Rr = make_recip(r), Rr2 = make_recip(sq(r));
   const Recip RpsiB = const_recip(P.a_psiB, P.a_inv_psiB);
   const double br = div(PsiZ, Rr), bz = div(-PsiR, Rr), bphi = div(RBphi, Rr);
@@ -562,7 +587,7 @@ RAYS_DEV int axisym_fields(const DevParams& P, const double rvec[3], double bvec
     if (P.a_n_model == RAYS_AXI_N_PARABOLIC) {
       parabolic_prof<UE>(psiN, P.a_d_scrape, P.a_an1, P.a_an2, dens, dd_psi);
     } else {
-      if (psiN <= 1.0) spl1_fp(P.a_ne_grid, P.a_ne_fspl, P.a_n_ne, psiN, dens, dd_psi);
+      if (psiN <= 1.0) spl1_tab(P, P.a_ne_grid, P.a_ne_fspl, P.a_n_ne, psiN, dens, dd_psi);
       if (dens < P.a_d_scrape) {
         dens = P.a_d_scrape;
         dd_psi = 0.;
@@ -600,8 +625,8 @@ RAYS_DEV int axisym_fields(const DevParams& P, const double rvec[3], double bvec
     } else if (m == RAYS_AXI_T_SPLINE) {
       double Te = 0., dTe = 0., Ti = 0., dTi = 0.;
       if (psiN <= 1.0) {
-        spl1_fp(P.a_te_grid, P.a_te_fspl, P.a_n_te, psiN, Te, dTe);
-        spl1_fp(P.a_ti_grid, P.a_ti_fspl, P.a_n_ti, psiN, Ti, dTi);
+        spl1_tab(P, P.a_te_grid, P.a_te_fspl, P.a_n_te, psiN, Te, dTe);
+        spl1_tab(P, P.a_ti_grid, P.a_ti_fspl, P.a_n_ti, psiN, Ti, dTi);
       }
       if (Te < P.a_T_scrape) { Te = P.a_T_scrape; dTe = 0.; }
       if (Ti < P.a_T_scrape) { Ti = P.a_T_scrape; dTi = 0.; }

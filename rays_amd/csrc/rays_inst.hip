@@ -42,7 +42,8 @@ hipError_t launch_one(const DevParams& P, const TraceArgs& A, hipStream_t stream
 #ifdef RAYS_RK4_DIRECT_STORES
     constexpr size_t lds = 0;
 #else
-    constexpr size_t lds = PointWindow<NV>::kLdsBytes;  // rays_trace.hpp (0 unless nv = 7 | 8)
+    // rays_trace.hpp: the point window (0 unless nv = 7 | 8) + the eqdsk 1-D tables where there is room
+    constexpr size_t lds = PointWindow<NV>::kLdsBytes + eq_tab_lds_bytes<EQ, NV>();
 #endif
     return launch_persistent(rk4_trace_kernel<EQ, NS, DERIV, NV>, lds, P, A, stream, grid_blocks);
   }
@@ -57,11 +58,16 @@ hipError_t launch_one(const DevParams& P, const TraceArgs& A, hipStream_t stream
 #else
 #define RAYS_KNAME "sg_trace_kernel"
 #endif
+#if RAYS_INST_SOLVER == 0
+#define RAYS_SG_FAR(NV) 0
+#else
+#define RAYS_SG_FAR(NV) sg_far_doubles_per_lane<NV>()
+#endif
 #define RAYS_ENTRY(NS, NV) \
-  { RAYS_INST_SOLVER, EQ, NS, DERIV, NV, 1, RAYS_KNAME "<" RAYS_STR(RAYS_INST_EQT) ", " #NS ", " RAYS_STR(RAYS_INST_DERIV) ", " #NV ">", &launch_one<NS, NV> }
+  { RAYS_INST_SOLVER, EQ, NS, DERIV, NV, 1, RAYS_SG_FAR(NV), RAYS_KNAME "<" RAYS_STR(RAYS_INST_EQT) ", " #NS ", " RAYS_STR(RAYS_INST_DERIV) ", " #NV ">", &launch_one<NS, NV> }
 // two-waves-per-SIMD build of an RK4 kernel (large fans; rays_rk4.hpp)
 #define RAYS_ENTRY_OCC2(NS, NV) \
-  { RAYS_INST_SOLVER, EQ, NS, DERIV, NV, 2, "rk4_trace_kernel_w2<" RAYS_STR(RAYS_INST_EQT) ", " #NS ", " RAYS_STR(RAYS_INST_DERIV) ", " #NV ">", &launch_one<NS, NV, 2> }
+  { RAYS_INST_SOLVER, EQ, NS, DERIV, NV, 2, 0, "rk4_trace_kernel_w2<" RAYS_STR(RAYS_INST_EQT) ", " #NS ", " RAYS_STR(RAYS_INST_DERIV) ", " #NV ">", &launch_one<NS, NV, 2> }
 
 const KernelEntry kEntries[] = {
 #ifdef RAYS_INST_FAST  // developer builds (make FAST=1): electrons + one ion species only

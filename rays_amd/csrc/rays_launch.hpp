@@ -22,6 +22,7 @@ enum { SOLVER_RK4 = 0, SOLVER_SG = 1 };
 struct KernelEntry {
   int solver, eq, ns, deriv, nv;  // eq = equilibrium model | kEqUnitExp (the kernels' EQ argument)
   int occ;                        // waves per SIMD the kernel is built for (RK4: 1 and, for the common shapes, 2)
+  int sg_far_per_lane;            // SG: doubles per lane of the upper-tier workspace (TraceArgs::sg_far); RK4: 0
   const char* name;
   // Launches on `stream` with a grid sized for full residency (persistent waves + lane refill).
   hipError_t (*launch)(const DevParams&, const TraceArgs&, hipStream_t stream, int* grid_blocks);
@@ -90,6 +91,7 @@ inline hipError_t launch_persistent(Kernel kernel, size_t lds_bytes, const DevPa
   const long long need = ((long long)A.nray + kBlock - 1) / kBlock;
   long long resident = (long long)cached_blocks_per_cu * cached_cus;
   int blocks = (int)(need < resident ? need : resident);
+  if (A.sg_far && (long long)blocks * kBlock > A.sg_far_lanes) blocks = (int)(A.sg_far_lanes / kBlock);
   if (blocks < 1) blocks = 1;
   if (grid_blocks) *grid_blocks = blocks;
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), lds_bytes, stream, P, A);

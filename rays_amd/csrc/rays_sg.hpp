@@ -76,21 +76,27 @@ enum : int {
 //
 // SG_ode restarts the integrator on every output interval (SG_ode_m.f90:118-122), so the order
 // stays low: k <= 4 in 99.5 % and k <= 6 in 99.97 % of the steps of the Solovev fans.  Storage is
-// therefore tiered by index, the fast tiers holding everything k <= 6 touches:
-//   coefficient entries 1..8        LDS, lane-interleaved (element e of lane L at col[e * 64])
-//   coefficient entries 9..13       private memory (scratch)
-//   phi rows 1..4                   registers: every loop over rows is unrolled over q = 1..4 with
-//                                   the lane's bounds as predicates and a wave-uniform skip
-//   phi rows 5..4+LR (LR = 30/nv)   LDS
-//   phi rows above                  private memory (scratch)
-// LDS per lane: 6 x 8 + LR x nv <= 78 doubles -> at most 156 KB per 4-wave workgroup, so the SG
-// kernel stages no trajectory points in LDS: it records one point per ~30 trips and the lane
-// writes it straight to HBM.
+// therefore tiered by index:
+//   coefficient entries 1..6          LDS, lane-interleaved (element e of lane L at col[e * 64])
+//   phi rows 1..2                     registers: every loop over rows is unrolled over q with the lane's
+//                                     bounds as predicates and a wave-uniform skip
+//   phi rows 3..2+LR (LR = 44/nv)     LDS
+//   everything above, the round-off   the launch's global workspace (TraceArgs::sg_far, [slot][lane], so a wave's
+//   rows 15-16 and y of SG_ode        access coalesces); reached in < 1 % of the steps, except rows 15-16, which
+//                                     are read and written once per step
+// No private arrays: a dynamically indexed private array is scratch memory, and with it came 0.9-1.1 KB of
+// scratch per lane, 115-180 SGPR spills and an HBM write stream 12x the trajectory's (round 1).  Now the kernels
+// have 0-100 B of scratch per lane.  LDS per lane: 36 + LR x nv <= 80 doubles = the CU's 160 KB for its four waves,
+// so the SG kernel stages no trajectory points in LDS: it records one point per ~30 trips and the lane writes it
+// straight to HBM.
 // ---------------------------------------------------------------------------------------------
 // (the RAYS_SG_* overrides exist for tests/hip_emul, which shrinks the fast tiers so that ordinary
 // rays cross every tier boundary)
 #ifndef RAYS_SG_TIER
-#define RAYS_SG_TIER 8
+#define RAYS_SG_TIER 6  // entries 1..k+1 (k+2 in intrp) are touched at order k
+// measured on MI355X (cfg5 eqdsk 256k rays nv = 8 | cfg3 Solovev 64k nv = 7, ms per pass), round-off rows in the
+// workspace: tier 5 -> 112.6 | 336.2, tier 6 -> 111.0 | 318.6, tier 8 -> 114.3 | 342.8; round-off rows in LDS instead
+// (fewer phi rows fit): tier 5 -> 118.3 | 333.5, tier 7 -> 135.6 | 343.9.  What decides is how many phi rows fit.
 #endif
 #ifndef RAYS_SG_REG_ROWS
 #define RAYS_SG_REG_ROWS 2  // measured on the 256k-ray eqdsk fan: 2 | 4 | 6 | 8 register rows -> 119 | 125 | 168 | 320 ms
@@ -109,27 +115,41 @@ constexpr int sg_phi_lds_rows() {
 #ifdef RAYS_SG_LDS_ROWS
   return RAYS_SG_LDS_ROWS;
 #else
-  return 30 / NV < 1 ? 1 : 30 / NV;
+  // what the CU's LDS leaves: 80 doubles per lane - 6 coefficient arrays
+  return (80 - 6 * kSgTier) / NV < 1 ? 1 : (80 - 6 * kSgTier) / NV;
 #endif
 }
 constexpr int kSgPhiRegRows = RAYS_SG_REG_ROWS;
 
+// This lane's column of the launch's upper-tier workspace (TraceArgs::sg_far, element e at column[e * stride]).
+// Recomputed where it is needed (rare) from the kernel arguments instead of being carried in registers.
+RAYS_DEV double* sg_far_column(const TraceArgs& A_hot) {
+  return cold_args(A_hot).sg_far + ((long long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+RAYS_DEV long long sg_far_stride() { return (long long)gridDim.x * blockDim.x; }
+
 struct SgCoef {
   enum { PSI = 0, ALPHA, BETA, SIG, G, V, kArrays };
   sg_lds_ptr col;               // this lane's LDS column
-  double (*far)[14 - kSgTier];  // entries above the LDS tier (.. 14), private memory of the kernel
+  // entries above the LDS tier (.. 14): the lane's column of the launch's global workspace (TraceArgs::sg_far),
+  // element e at far[e * far_stride].  Not private memory: a dynamically indexed private array is scratch,
+  // and its mere presence cost the hot loop address arithmetic and spill slots next to it.
+  const TraceArgs* args;
+  static constexpr int kFarPerArray = 14 - kSgTier;
+  static constexpr int kFarDoubles = kArrays * kFarPerArray;
 
   struct Ref {  // reads / writes one entry through the tier it lives in
     const SgCoef* s;
     int arr, i;
     RAYS_DEV operator double() const {
-      return i <= kSgTier ? s->col[(arr * kSgTier + i - 1) * kWave] : s->far[arr][i - kSgTier - 1];
+      if (RAYS_RARE(i > kSgTier)) return sg_far_column(*s->args)[(arr * kFarPerArray + i - kSgTier - 1) * sg_far_stride()];
+      return s->col[(arr * kSgTier + i - 1) * kWave];
     }
     RAYS_DEV const Ref& operator=(double x) const {
-      if (i <= kSgTier)
-        s->col[(arr * kSgTier + i - 1) * kWave] = x;
+      if (RAYS_RARE(i > kSgTier))
+        sg_far_column(*s->args)[(arr * kFarPerArray + i - kSgTier - 1) * sg_far_stride()] = x;
       else
-        s->far[arr][i - kSgTier - 1] = x;
+        s->col[(arr * kSgTier + i - 1) * kWave] = x;
       return *this;
     }
     RAYS_DEV const Ref& operator=(const Ref& o) const { return *this = (double)o; }  // copies the VALUE
@@ -159,8 +179,21 @@ struct SgPhi {
   static_assert(R >= 2 && LR >= 1, "rows 1 and 2 are addressed directly (start of an interval)");
   double lo[R][NV];  // rows 1..R: registers (static indices only)
   sg_lds_ptr mid;    // rows R+1..R+LR: LDS, element (row, l) of this lane at mid[((row-R-1)*NV + l) * 64]
-  double (*hi)[NV];  // rows R+LR+1..16 -> hi[row - R - LR - 1]: a SEPARATE private array of the kernel,
-                     // so that its dynamic indexing does not drag lo[] into scratch memory with it
+  // phi(:,15) and phi(:,16) carry the propagated round-off of `step` (ode_RAYS.f90:1006-1011, 1131-1136) whenever
+  // the tolerance is within 100x of the round-off level -- every step of the BASELINE runs (1e-9).  They live in
+  // the workspace behind rows .. 14: one read and one write of each per step, issued well ahead of their use;
+  // LDS is worth more as phi rows (measurements at RAYS_SG_TIER above).
+  RAYS_DEV double* rnd_col() const { return sg_far_column(*args) + (SgCoef::kFarDoubles + kFarDoubles) * sg_far_stride(); }
+  RAYS_DEV double rnd15(int l) const { return rnd_col()[l * sg_far_stride()]; }
+  RAYS_DEV double rnd16(int l) const { return rnd_col()[(NV + l) * sg_far_stride()]; }
+  RAYS_DEV void set_rnd15(int l, double x) const { rnd_col()[l * sg_far_stride()] = x; }
+  RAYS_DEV void set_rnd16(int l, double x) const { rnd_col()[(NV + l) * sg_far_stride()] = x; }
+  const TraceArgs* args;  // rows R+LR+1..14: global workspace behind the coefficient tiers (see SgCoef)
+  static constexpr int kFarRows = 14 - R - LR;
+  static constexpr int kFarDoubles = kFarRows * NV;
+  RAYS_DEV double& far_at(int row, int l) const {
+    return sg_far_column(*args)[(SgCoef::kFarDoubles + (row - R - LR - 1) * NV + l) * sg_far_stride()];
+  }
 
   RAYS_DEV void load_far(int i, double out[NV]) const {  // i > R
     const int r = i - R - 1;
@@ -169,7 +202,7 @@ struct SgPhi {
       for (int l = 0; l < NV; l++) out[l] = mid[(r * NV + l) * kWave];
     } else {
 #pragma unroll
-      for (int l = 0; l < NV; l++) out[l] = hi[r - LR][l];
+      for (int l = 0; l < NV; l++) out[l] = far_at(i, l);
     }
   }
   RAYS_DEV void store_far(int i, const double in[NV]) {  // i > R
@@ -179,7 +212,7 @@ struct SgPhi {
       for (int l = 0; l < NV; l++) mid[(r * NV + l) * kWave] = in[l];
     } else {
 #pragma unroll
-      for (int l = 0; l < NV; l++) hi[r - LR][l] = in[l];
+      for (int l = 0; l < NV; l++) far_at(i, l) = in[l];
     }
   }
   RAYS_DEV void get(int i, double out[NV]) const {  // out = phi(:, i), i dynamic
@@ -336,6 +369,27 @@ struct SgPhi {
   }
 };
 
+// doubles per lane of the launch's global workspace (TraceArgs::sg_far): the tiers above LDS
+template <int NV>
+constexpr int sg_far_doubles_per_lane() {
+  return SgCoef::kFarDoubles + SgPhi<NV, kSgPhiRegRows, sg_phi_lds_rows<NV>()>::kFarDoubles + 2 * NV + NV;  // + round-off rows 15, 16 + y (below)
+}
+// y of SG_ode -- the ray state the reference's `ode` was last entered with or returned (the last completed output
+// point, or the state after a tolerance-inflation restart).  It is only READ when a ray stops (end_ray_vec), so
+// it lives in the workspace behind the upper tiers: written once per output interval, no registers.
+template <int NV>
+RAYS_DEV void sg_save_y(const TraceArgs& A_hot, const double y[NV]) {
+  double* c = sg_far_column(A_hot) + (sg_far_doubles_per_lane<NV>() - NV) * sg_far_stride();
+#pragma unroll
+  for (int l = 0; l < NV; l++) c[l * sg_far_stride()] = y[l];
+}
+template <int NV>
+RAYS_DEV void sg_load_y(const TraceArgs& A_hot, double y[NV]) {
+  const double* c = sg_far_column(A_hot) + (sg_far_doubles_per_lane<NV>() - NV) * sg_far_stride();
+#pragma unroll
+  for (int l = 0; l < NV; l++) y[l] = c[l * sg_far_stride()];
+}
+
 // gstr(1:13) -- single-precision literals widened to double (ode_RAYS.f90:776-779).  Indexed by the
 // lane's order: a select chain over compile-time constants (a table in global memory cost a waited
 // ~0.7 us load per use, four uses per step).
@@ -353,20 +407,20 @@ RAYS_DEV double gstr(int i) {
 
 template <int EQ, int NS, int DERIV, int NV>
 __global__ void __launch_bounds__(256)
-sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
+sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
+  DevParams P;  // working copy with the hot per-species constants in vector registers (rays_device.hpp)
+  hot_params<EQ, NS>(P_kernarg, P);
   extern __shared__ double lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
   constexpr int RR = kSgPhiRegRows, LR = sg_phi_lds_rows<NV>();
   const sg_lds_ptr lane_lds = (sg_lds_ptr)(lds + wave * SgLds<NV>::kDoublesPerWave + lane);
-  double coef_far[SgCoef::kArrays][14 - kSgTier];
   SgCoef S;
   S.col = lane_lds;
-  S.far = coef_far;
-  double phi_far[17 - RR - LR][NV];
   SgPhi<NV, RR, LR> F;  // divided differences phi(neqn,16)
   F.mid = lane_lds + SgLds<NV>::kPhiBase * kWave;
-  F.hi = phi_far;
+  S.args = &A_hot;  // the rarely touched upper tiers live in the launch's workspace (TraceArgs::sg_far)
+  F.args = &A_hot;
 
   const unsigned total_lanes = gridDim.x * blockDim.x;
   const long long npt = (long long)P.nstep_max + 1;
@@ -382,7 +436,9 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
   int nstep = 0;
   double sout = 0.;
   double ds_ray = P.ds;  // output step of this lane's run (a fused scan gives every run its own)
-  double vst[NV];   // v: the ray state at the last completed output point (y of SG_ode)
+  // (y of SG_ode, the state at the last completed output point, has no registers: between the interpolation
+  // that produces it and the `de` entry that consumes it, it IS yy; a copy for the day the ray stops is kept in
+  // the workspace, sg_save_y)
   double last_resid = 0., prev_resid = 0., maxr = -1.7976931348623157e308;
 
   // ---- per-lane integrator state (de / step locals that live across RHS evaluations) ----------
@@ -393,20 +449,23 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
   double rel_err = 0., abs_err = 0., releps = 0., abseps = 0., absdel = 0., tend = 0.;
   double p5eps = 0., round_ = 0., xold = 0., absh = 0., erk = 0., erkm1 = 0.;
   int k = 1, kold = 0, ns = 0, knew = 1, ifail = 0, nostep = 0, kle4 = 0;
+  int resume = SEG_WAIT;  // continuation segment deferred to the next trip (the rare DE_TOP -> CRASH edge)
   // Per-lane logicals are kept as bits of ONE integer VGPR rather than as `bool`s: a bool that is
   // live across the divergent continuation loop is a 64-bit lane mask in SGPRs, and with ~10 of
   // them the register allocator spills lane masks inside divergent control flow.
   unsigned fl = FL_START | FL_PHASE1 | FL_NORND | FL_FIRST;
 #pragma unroll
-  for (int i = 0; i < NV; i++) vst[i] = yy[i] = pp[i] = wt[i].d = wt[i].rc = 0.;
+  for (int i = 0; i < NV; i++) yy[i] = pp[i] = wt[i].d = wt[i].rc = 0.;
 
   SG_PROF_DECL
   while (__any(alive)) {
     SG_PROF(0);  // loop overhead, refill
     if (RAYS_RARE(need_init)) {  // ray_tracing.f90:77-93, SG_ode_m.f90:73-85
       const TraceArgs& A = cold_args(A_hot);  // rays_trace.hpp
-      start_ray<EQ, NS, NV>(P, A, ray, vst, sout, ds_ray);
+      start_ray<EQ, NS, NV>(P, A, ray, yy, sout, ds_ray);
+      sg_save_y<NV>(A_hot, yy);
       pc = PC_CHECK;
+      resume = SEG_WAIT;
       fl |= FL_FIRST;
       nstep = 0;
       t = sout;
@@ -430,13 +489,14 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
     // slot).  Served lanes move to the other phase, so the wave falls into step after one trip and
     // a lane idles about once per output interval (an interval has an odd number of evaluations).
     const bool in_f2 = pc == PC_F2;
-    const int n_f2 = __popcll(__ballot(alive && in_f2)), n_other = __popcll(__ballot(alive && !in_f2));
+    const bool wants_rhs = alive && resume == SEG_WAIT;  // a lane with a deferred segment needs no evaluation
+    const int n_f2 = __popcll(__ballot(wants_rhs && in_f2)), n_other = __popcll(__ballot(wants_rhs && !in_f2));
     const bool serve_f2 = n_f2 > n_other;
-    const bool act = alive && (in_f2 == serve_f2);
+    const bool act = wants_rhs && (in_f2 == serve_f2);
     // RHS input: the recorded state (PC_CHECK), the predicted p (PC_F2), else the current yy
     double win[NV];
 #pragma unroll
-    for (int l = 0; l < NV; l++) win[l] = pc == PC_F2 ? pp[l] : (pc == PC_CHECK ? vst[l] : yy[l]);
+    for (int l = 0; l < NV; l++) win[l] = pc == PC_F2 ? pp[l] : yy[l];
     SG_PROF(1);  // init + phase vote
     if (act) rhs_eval<EQ, NS, DERIV, NV>(P, win, pc == PC_CHECK, resid, cs_flag, cs_stop, code, f);
 #ifdef RAYS_SG_PROFILE
@@ -448,13 +508,19 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
     // ---- per-lane continuation -------------------------------------------------------------------
     int stop = 0;
     int done = 0;
+    // Control flow is kept FLAT: the segments below are sequential `if (seg == ...)` blocks on the top level of
+    // the wave loop, in pipeline order, and run once per trip.  (An enclosing `if (act)` and a `while (seg !=
+    // SEG_WAIT)` around them made every join a merge point of the whole integrator state: ~160 register moves
+    // per join and trip.)  The one backward edge, DE_TOP -> CRASH (the step size underflowed or the tolerance is
+    // below the round-off level: rare), is deferred to the next trip through `resume`.
+    int seg = resume;
+    resume = SEG_WAIT;
+    int have_f = 0;  // f(x, yy) for start = true is already in f[]
     if (act) {
-      int seg;
-      int have_f = 0;  // f(x, yy) for start = true is already in f[]
       if (pc == PC_CHECK) {
         seg = SEG_DE_BEGIN;
         if (RAYS_RARE(fl & FL_FIRST)) {  // ray_tracing.f90:92-112
-          record_point<NV>(cold_args(A_hot), (long long)ray * npt, vst, 0.);
+          record_point<NV>(cold_args(A_hot), (long long)ray * npt, yy, 0.);
           fl &= ~FL_FIRST;
           if (RAYS_RARE(cs_stop)) {
             const TraceArgs& A = cold_args(A_hot);
@@ -470,13 +536,13 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
             seg = SEG_WAIT;
           }
         } else {
-          // the interval completed: vst is y(tout)  (ray_tracing.f90:212-243)
+          // the interval completed: yy is y(tout)  (ray_tracing.f90:212-243)
           if (RAYS_RARE(cs_stop)) {
             stop = cs_flag;
             seg = SEG_STOP;
           } else {
             nstep = nstep + 1;
-            record_point<NV>(cold_args(A_hot), (long long)ray * npt + nstep, vst, resid);
+            record_point<NV>(cold_args(A_hot), (long long)ray * npt + nstep, yy, resid);
             if (fabs(last_resid) > maxr) maxr = fabs(last_resid);
             prev_resid = last_resid;
             last_resid = resid;
@@ -503,12 +569,13 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
       } else {
         seg = SEG_AFTER_F3;
       }
+    }
 
-      // Continuation segments in pipeline order: a lane falls through AFTER_F3 -> DE_TOP -> COEF (or
-      // CHECK -> DE_BEGIN -> DE_TOP -> START_DONE -> COEF) in ONE pass, so each segment's code runs
-      // at most once per trip for the whole wave; only the rare DE_TOP -> CRASH edge goes round again.
-      SG_PROF(3);  // CHECK bookkeeping
-      while (seg != SEG_WAIT) {
+    // Continuation segments in pipeline order: a lane falls through AFTER_F3 -> DE_TOP -> COEF (or
+    // CHECK -> DE_BEGIN -> DE_TOP -> START_DONE -> COEF) in ONE pass.
+    SG_PROF(3);  // CHECK bookkeeping
+    {
+      {
         if (seg == SEG_AFTER_F2) {
           if (RAYS_RARE(code)) {  // :1020
             stop = code;
@@ -554,9 +621,9 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
               if (!(fl & FL_NORND)) {
 #pragma unroll
                 for (int l = 0; l < NV; l++) {
-                  const double rho = hg * (f[l] - F.lo[0][l]) - F.hi[16 - RR - LR - 1][l];
+                  const double rho = hg * (f[l] - F.lo[0][l]) - F.rnd16(l);
                   yy[l] = pp[l] + rho;
-                  F.hi[15 - RR - LR - 1][l] = (yy[l] - pp[l]) - rho;
+                  F.set_rnd15(l, (yy[l] - pp[l]) - rho);
                 }
               } else {
 #pragma unroll
@@ -660,8 +727,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
         if (RAYS_RARE(seg == SEG_CRASH)) {  // de returns iflag = 3 (ode_RAYS.f90:566-575), SG_ode_m.f90:139-149
           rel_err = eps * releps;
           abs_err = eps * abseps;
-#pragma unroll
-          for (int i = 0; i < NV; i++) vst[i] = yy[i];  // y = yy
+          sg_save_y<NV>(A_hot, yy);  // y = yy
           t = x;
           const double total_error = fabs(rel_err) + fabs(abs_err);
           if (total_error > P.sg_error_limit) {
@@ -674,7 +740,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
         }
         SG_PROF(6);
         if (seg == SEG_DE_BEGIN) {
-          // ---- de parameter tests + restart (ode_RAYS.f90:423-505); y == vst, t, tout set ----
+          // ---- de parameter tests + restart (ode_RAYS.f90:423-505); y == yy, t, tout set ----
           if (t == tout) {
             stop = RAYS_STOP_SG_T_EQ_TOUT;
             seg = SEG_STOP;
@@ -697,8 +763,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
               abseps = abs_err / eps;
               fl |= FL_START;  // :497-505
               x = t;
-#pragma unroll
-              for (int i = 0; i < NV; i++) yy[i] = vst[i];
+              // (yy = y: they are the same registers)
               h = copysign(fmax(fabs(tout - x), fouru * fabs(x)), tout - x);
               seg = SEG_DE_TOP;
             }
@@ -728,14 +793,14 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
             for (int l = 0; l < NV; l++) yout[l] = 0.0;
             F.interp(ki, [&](int i) { return S.gi(i); }, yout);
 #pragma unroll
-            for (int l = 0; l < NV; l++) vst[l] = yy[l] + hi * yout[l];  // y = yout
+            for (int l = 0; l < NV; l++) yy[l] = yy[l] + hi * yout[l];  // y = yout
+            sg_save_y<NV>(A_hot, yy);
             t = tout;
             pc = PC_CHECK;
             seg = SEG_WAIT;
           } else if (maxnum <= nostep) {  // :536-548
             stop = (fl & FL_STIFF) ? RAYS_STOP_SG_STIFF : RAYS_STOP_SG_MAXNUM;
-#pragma unroll
-            for (int i = 0; i < NV; i++) vst[i] = yy[i];  // y = yy; t = x
+            sg_save_y<NV>(A_hot, yy);  // y = yy; t = x
             t = x;
             seg = SEG_STOP;
           } else {
@@ -805,7 +870,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
             if (p5eps <= 100.0 * round_) {
               fl &= ~FL_NORND;
 #pragma unroll
-              for (int l = 0; l < NV; l++) F.hi[15 - RR - LR - 1][l] = 0.0;
+              for (int l = 0; l < NV; l++) F.set_rnd15(l, 0.0);
             }
             ifail = 0;
             seg = SEG_COEF;
@@ -899,9 +964,9 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
           if (!(fl & FL_NORND)) {
 #pragma unroll
             for (int l = 0; l < NV; l++) {
-              const double tau = h * pp[l] - F.hi[15 - RR - LR - 1][l];
+              const double tau = h * pp[l] - F.rnd15(l);
               pp[l] = yy[l] + tau;
-              F.hi[16 - RR - LR - 1][l] = (pp[l] - yy[l]) - tau;
+              F.set_rnd16(l, (pp[l] - yy[l]) - tau);
             }
           } else {
 #pragma unroll
@@ -918,6 +983,7 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
           done = 1;
           seg = SEG_WAIT;
         }
+        if (RAYS_RARE(seg != SEG_WAIT)) resume = seg;  // SEG_CRASH entered from DE_TOP: next trip
       }
 
       SG_PROF(11);
@@ -925,9 +991,12 @@ sg_trace_kernel(const DevParams P, const TraceArgs A_hot) {
         const TraceArgs& A = cold_args(A_hot);
         A.npoints[ray] = nstep + 1;
         A.stop_code[ray] = stop;
-        if (A.end_ray_vec)
+        if (A.end_ray_vec) {
+          double yend[NV];
+          sg_load_y<NV>(A_hot, yend);
 #pragma unroll
-          for (int i = 0; i < NV; i++) A.end_ray_vec[(long long)ray * NV + i] = vst[i];
+          for (int i = 0; i < NV; i++) A.end_ray_vec[(long long)ray * NV + i] = yend[i];
+        }
         if (A.end_residuals) A.end_residuals[ray] = nstep >= 1 ? prev_resid : 0.;
         if (A.max_residuals) A.max_residuals[ray] = maxr;
       }

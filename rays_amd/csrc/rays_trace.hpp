@@ -40,6 +40,10 @@ struct TraceArgs {
   // with step ds_run[r]; rays_per_run = 0: one run, ds from the parameter block.
   const double* __restrict__ ds_run;       // [nrun]
   int rays_per_run;
+  // SG kernels: workspace for the integrator's rarely used upper storage tiers (rays_sg.hpp), [doubles per
+  // lane][sg_far_lanes]; the launcher never starts more lanes than sg_far_lanes
+  double* __restrict__ sg_far;
+  long long sg_far_lanes;
 };
 
 // Start of a ray: initialize_ode_vector (or the caller's v0), the ray parameter and the run's step.
@@ -186,5 +190,15 @@ struct PointWindow {
     for (int u = K ? 0 : pr; u < pr + m; u++) gr[u] = res[u * kStride];
   }
 };
+
+// LDS for the staged 1-D spline tables of the eqdsk equilibrium (DevParams::a_lds_tab), behind the point
+// window: kernels whose window leaves room (nv = 8: residual(:) only; nv = 12 | 13: none) get 32 KB (+ a pad that
+// keeps the block off LDS address 0, which means "not staged").
+constexpr size_t kEqTabPad = 64, kEqTabBytes = 32768;
+template <int EQ, int NV>
+constexpr size_t eq_tab_lds_bytes() {
+  return ((EQ & 3) == RAYS_EQ_AXISYM && PointWindow<NV>::kLdsBytes + kEqTabPad + kEqTabBytes <= 160 * 1024)
+             ? kEqTabPad + kEqTabBytes : 0;
+}
 
 }  // namespace rays

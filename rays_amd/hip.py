@@ -12,6 +12,13 @@ import numpy as np
 
 from .params import AxisymTables, RaysFan, RaysParams, axisym_tables_struct
 
+
+class DeviceResult(C.Structure):
+    """rays_device_result_t (include/rays_hip.h)"""
+    _fields_ = [("device", C.c_int32), ("nray", C.c_int32), ("ray_vec", C.c_void_p), ("residual", C.c_void_p),
+                ("npoints", C.c_void_p), ("stop_code", C.c_void_p), ("end_ray_vec", C.c_void_p),
+                ("end_residuals", C.c_void_p), ("max_residuals", C.c_void_p)]
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RAYS_HIP_LIB") or os.path.join(_HERE, "lib", "librays_hip.so")
 
@@ -19,10 +26,10 @@ LIB_PATH = os.environ.get("RAYS_HIP_LIB") or os.path.join(_HERE, "lib", "librays
 EXPORTED_SYMBOLS = (
     "rays_hip_init", "rays_hip_init_devices", "rays_hip_finalize", "rays_hip_device_count", "rays_hip_sizeof_params",
     "rays_hip_last_error", "rays_hip_set_zfun_table", "rays_hip_set_axisym_tables",
-    "rays_hip_stop_flag_text", "rays_hip_check_params", "rays_hip_trace", "rays_hip_trace_device", "rays_hip_scan_device", "rays_hip_ode_step_device",
+    "rays_hip_stop_flag_text", "rays_hip_check_params", "rays_hip_trace", "rays_hip_trace_gather", "rays_hip_result_to_host", "rays_hip_trace_device", "rays_hip_scan_device", "rays_hip_ode_step_device",
     "rays_hip_kernel_name", "rays_hip_kernel_name_for", "rays_hip_probe", "rays_hip_pack_device", "rays_hip_unpack_device",
     "rays_hip_sizeof_fan", "rays_hip_ray_init", "rays_hip_ray_init_device",
-    "rays_hip_set_rho_table", "rays_hip_deposition_device",
+    "rays_hip_set_rho_table", "rays_hip_deposition_device", "rays_hip_deposition",
 )
 
 _lib = None
@@ -69,6 +76,10 @@ def load():
     lib.rays_hip_kernel_name_for.argtypes = [pp, C.c_int]
     lib.rays_hip_trace.restype = C.c_int
     lib.rays_hip_trace.argtypes = [pp, C.c_int, dp, dp, dp, dp, ip, ip, dp, dp, dp, dp]
+    lib.rays_hip_trace_gather.restype = C.c_int
+    lib.rays_hip_trace_gather.argtypes = [pp, C.c_int, dp, dp, C.POINTER(DeviceResult)]
+    lib.rays_hip_result_to_host.restype = C.c_int
+    lib.rays_hip_result_to_host.argtypes = [pp, C.POINTER(DeviceResult), dp, dp, ip, ip, dp, dp, dp]
     lib.rays_hip_trace_device.restype = C.c_int
     lib.rays_hip_trace_device.argtypes = [pp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
     lib.rays_hip_scan_device.restype = C.c_int
@@ -91,6 +102,8 @@ def load():
     lib.rays_hip_ray_init_device.argtypes = [pp, fp, C.c_int, vp, vp, ip, vp]
     lib.rays_hip_set_rho_table.restype = C.c_int
     lib.rays_hip_set_rho_table.argtypes = [dp, dp, C.c_int]
+    lib.rays_hip_deposition.restype = C.c_int
+    lib.rays_hip_deposition.argtypes = [pp, C.c_int, C.c_int, C.c_int, dp, ip, dp, dp, dp]
     lib.rays_hip_deposition_device.restype = C.c_int
     lib.rays_hip_deposition_device.argtypes = [pp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     _lib = lib
@@ -205,6 +218,18 @@ def init_devices(device_ids):
         raise RaysHipError("rays_hip_init_devices: " + last_error())
 
 
+def deposition_host(p: RaysParams, which: str, n_bins: int, ray_vec, npoints, initial_ray_power):
+    """rays_hip_deposition: host arrays in (the ray_results_m image), (work[nray][n_bins], profile[n_bins]) out."""
+    ray_vec = np.ascontiguousarray(ray_vec, dtype=np.float64)
+    npoints = np.ascontiguousarray(npoints, dtype=np.int32)
+    power = np.ascontiguousarray(initial_ray_power, dtype=np.float64)
+    nray = len(npoints)
+    work, prof = np.zeros((nray, n_bins)), np.zeros(n_bins)
+    _check(load().rays_hip_deposition(C.byref(p), DEP_PROFILES[which], int(n_bins), nray, _dp(ray_vec), _ip(npoints),
+                                      _dp(power), _dp(work), _dp(prof)), "rays_hip_deposition")
+    return work, prof
+
+
 def trace_host(p: RaysParams, rvec0, rindex_vec0, ngpu: int = 0, out: dict = None) -> dict:
     """rays_hip_trace: host numpy arrays in / out (the Fortran drop-in entry).  `out`: the result
     arrays of an earlier call over the same fan to write into (the library overwrites points
@@ -232,6 +257,29 @@ def trace_host(p: RaysParams, rvec0, rindex_vec0, ngpu: int = 0, out: dict = Non
     _check(rc, "rays_hip_trace")
     out["elapsed_s"] = el.value
     return out
+
+
+def trace_gather(p: RaysParams, rvec0, rindex_vec0, to_host: bool = True):
+    """rays_hip_trace_gather: rays sharded over the selected devices, trajectories gathered on the root device
+    with RCCL.  Returns the device-resident result block and, with to_host, the arrays copied out."""
+    lib = load()
+    ensure_tables(p)
+    rvec0 = np.ascontiguousarray(rvec0, dtype=np.float64)
+    rindex_vec0 = np.ascontiguousarray(rindex_vec0, dtype=np.float64)
+    res = DeviceResult()
+    _check(lib.rays_hip_trace_gather(C.byref(p), len(rvec0), _dp(rvec0), _dp(rindex_vec0), C.byref(res)),
+           "rays_hip_trace_gather")
+    if not to_host:
+        return res, None
+    nray, nv, npt = len(rvec0), p.nv, p.nstep_max + 1
+    out = dict(ray_vec=np.zeros((nray, npt, nv)), residual=np.zeros((nray, npt)),
+               npoints=np.zeros(nray, dtype=np.int32), stop_code=np.zeros(nray, dtype=np.int32),
+               end_ray_vec=np.zeros((nray, nv)), end_residuals=np.zeros(nray), max_residuals=np.zeros(nray))
+    _check(lib.rays_hip_result_to_host(C.byref(p), C.byref(res), _dp(out["ray_vec"]), _dp(out["residual"]),
+                                       _ip(out["npoints"]), _ip(out["stop_code"]), _dp(out["end_ray_vec"]),
+                                       _dp(out["end_residuals"]), _dp(out["max_residuals"])),
+           "rays_hip_result_to_host")
+    return res, out
 
 
 def trace_device(p: RaysParams, nray: int, d_rvec0: int, d_rindex_vec0: int, d_ray_vec: int,

@@ -202,41 +202,83 @@ def read_results_LD(path: str) -> Dict[str, Any]:
     return out
 
 
+_NC_TYPE = {"char": (2, "S1", 1), "int": (4, ">i4", 4), "float": (5, ">f4", 4), "double": (6, ">f8", 8)}
+
+
+def _write_netcdf_classic(path: str, dims, gatts, variables) -> None:
+    """A NetCDF classic file (CDF-1; CDF-2 = 64-bit offsets when a variable starts beyond 2 GiB) with
+    dimensions, global char attributes and fixed-size variables laid out IN DEFINITION ORDER, as the netCDF
+    library lays out what the reference's write_results_NC defines (scipy's writer re-orders the variables).
+    dims: [(name, size)]; gatts: [(name, text)]; variables: [(name, type, (dim names), array)]."""
+    import struct
+
+    def pad4(b: bytes) -> bytes:
+        return b + b"\0" * (-len(b) % 4)
+
+    def nm(sname: str) -> bytes:
+        e = sname.encode()
+        return struct.pack(">I", len(e)) + pad4(e)
+
+    dim_index = {d[0]: i for i, d in enumerate(dims)}
+    blobs = []
+    for vname, typ, vdims, data in variables:
+        code, dt, size = _NC_TYPE[typ]
+        arr = np.asarray(data).astype(dt) if typ != "char" else np.asarray(data, dtype="S1")
+        want = tuple(dict(dims)[d] for d in vdims)
+        arr = np.ascontiguousarray(arr).reshape(want) if arr.size == int(np.prod(want, dtype=np.int64)) else arr
+        if arr.shape != want:
+            raise ValueError(f"{vname}: shape {arr.shape} != {want}")
+        blobs.append(pad4(arr.tobytes()))
+    for off_bytes in (4, 8):
+        head = [b"CDF" + bytes([1 if off_bytes == 4 else 2]), struct.pack(">I", 0)]
+        head.append(struct.pack(">II", 0x0A, len(dims)) if dims else struct.pack(">II", 0, 0))
+        for dname, size in dims:
+            head.append(nm(dname) + struct.pack(">I", size))
+        head.append(struct.pack(">II", 0x0C, len(gatts)) if gatts else struct.pack(">II", 0, 0))
+        for aname, text in gatts:
+            e = text.encode()
+            head.append(nm(aname) + struct.pack(">II", 2, len(e)) + pad4(e))
+        head.append(struct.pack(">II", 0x0B, len(variables)) if variables else struct.pack(">II", 0, 0))
+        var_heads = []
+        for (vname, typ, vdims, _), blob in zip(variables, blobs):
+            h = nm(vname) + struct.pack(">I", len(vdims)) + b"".join(struct.pack(">I", dim_index[d]) for d in vdims)
+            h += struct.pack(">II", 0, 0)  # no variable attributes
+            h += struct.pack(">I", _NC_TYPE[typ][0]) + struct.pack(">I", min(len(blob), 0xFFFFFFFF))
+            var_heads.append(h)
+        hlen = sum(len(x) for x in head) + sum(len(h) + off_bytes for h in var_heads)
+        begins, pos = [], hlen
+        for blob in blobs:
+            begins.append(pos)
+            pos += len(blob)
+        if off_bytes == 8 or all(bg < (1 << 31) for bg in begins):
+            break
+    with open(path, "wb") as f:
+        f.write(b"".join(head))
+        for h, bg in zip(var_heads, begins):
+            f.write(h + struct.pack(">I" if off_bytes == 4 else ">Q", bg))
+        for blob in blobs:
+            f.write(blob)
+
+
 def write_results_NC(path: str, r: RunResults) -> None:
-    """write_results_NC (ray_results_m.f90:171-249): same dimension and variable names and types
-    (ray_vec, residual double; the per-ray summaries NF90_FLOAT; ray_stop_flag char[number_of_rays][60]);
-    ray_vec / residual cut to maxval(npoints)."""
-    from scipy.io import netcdf_file
-
+    """write_results_NC (ray_results_m.f90:171-249): the same dimensions (:205-209) and variables (:212-224) in the
+    same definition order with the same NetCDF types (ray_vec, residual double; the per-ray summaries NF90_FLOAT;
+    ray_stop_flag char [number_of_rays][60]; the Fortran dimension lists reversed into the file's C order), the
+    global attribute RAYS_run_label (:227); ray_vec / residual cut to maxval(npoints) (:202)."""
     npt = int(r.npoints.max()) if r.number_of_rays else 0
-    nbytes = 8 * r.number_of_rays * npt * (r.dim_v_vector + 1)
-    f = netcdf_file(path, "w", version=1 if nbytes < (1 << 31) - (1 << 20) else 2)
-    try:
-        f.RAYS_run_label = r.RAYS_run_label.ljust(_FLAG_LEN)
-        f.createDimension("number_of_rays", r.number_of_rays)
-        f.createDimension("max_number_of_points", npt)
-        f.createDimension("dim_v_vector", r.dim_v_vector)
-        f.createDimension("d8", 8)
-        f.createDimension("d60", _FLAG_LEN)
-        R, P, V = "number_of_rays", "max_number_of_points", "dim_v_vector"
-
-        def var(name, typ, dims, data):
-            v = f.createVariable(name, typ, dims)
-            v[...] = data
-
-        var("date_vector", "i", ("d8",), r.date_vector)
-        var("ray_vec", "d", (R, P, V), r.ray_vec[:, :npt, :])
-        var("residual", "d", (R, P), r.residual[:, :npt])
-        var("npoints", "i", (R,), r.npoints)
-        for k in ("initial_ray_power", "ray_trace_time", "end_residuals", "max_residuals", "end_ray_parameter"):
-            var(k, "f", (R,), getattr(r, k).astype(np.float32))
-        var("start_ray_vec", "f", (R, V), r.start_ray_vec.astype(np.float32))
-        var("end_ray_vec", "f", (R, V), r.end_ray_vec.astype(np.float32))
-        flags = np.array([list(s[:_FLAG_LEN].ljust(_FLAG_LEN)) for s in r.ray_stop_flag], dtype="S1")
-        var("ray_stop_flag", "c", (R, "d60"), flags.reshape(r.number_of_rays, _FLAG_LEN))
-        var("total_trace_time", "f", (), np.float32(r.total_trace_time))
-    finally:
-        f.close()
+    R, P, V = "number_of_rays", "max_number_of_points", "dim_v_vector"
+    dims = [(R, r.number_of_rays), (P, npt), (V, r.dim_v_vector), ("d8", 8), ("d60", _FLAG_LEN)]
+    flags = np.array([list(s[:_FLAG_LEN].ljust(_FLAG_LEN)) for s in r.ray_stop_flag], dtype="S1")
+    variables = [("date_vector", "int", ("d8",), r.date_vector),
+                 ("ray_vec", "double", (R, P, V), r.ray_vec[:, :npt, :]),
+                 ("residual", "double", (R, P), r.residual[:, :npt]),
+                 ("npoints", "int", (R,), r.npoints)]
+    for k in ("initial_ray_power", "ray_trace_time", "end_residuals", "max_residuals", "end_ray_parameter"):
+        variables.append((k, "float", (R,), getattr(r, k)))
+    variables += [("start_ray_vec", "float", (R, V), r.start_ray_vec), ("end_ray_vec", "float", (R, V), r.end_ray_vec),
+                  ("ray_stop_flag", "char", (R, "d60"), flags.reshape(r.number_of_rays, _FLAG_LEN)),
+                  ("total_trace_time", "float", (), np.float32(r.total_trace_time))]
+    _write_netcdf_classic(path, dims, [("RAYS_run_label", r.RAYS_run_label.ljust(_FLAG_LEN))], variables)
 
 
 def read_results_NC(path: str) -> Dict[str, Any]:

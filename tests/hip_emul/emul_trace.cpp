@@ -80,6 +80,8 @@ extern "C" int rays_emul_trace_ex(const rays_params_t* p, int nray, const double
   unsigned counter = 0;
   rays::TraceArgs A = rays::TraceArgs();
   A.v0 = v0; A.s0 = s0; A.ds_run = ds_run; A.rays_per_run = rays_per_run;
+  std::vector<double> sg_far(512, 0.0);  // one lane: the SG kernels' upper-tier workspace
+  A.sg_far = sg_far.data(); A.sg_far_lanes = 1;
   A.nray = nray; A.rvec0 = rvec0; A.rindex_vec0 = rindex_vec0; A.ray_vec = ray_vec;
   A.residual = residual; A.npoints = npoints; A.stop_code = stop_code; A.end_ray_vec = end_ray_vec;
   A.end_residuals = end_residuals; A.max_residuals = max_residuals; A.next_ray = &counter;

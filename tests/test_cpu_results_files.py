@@ -121,3 +121,103 @@ def test_kernel_source_on_host_writes_the_reference_file(tmp_path):
     for k in ARRAYS:
         np.testing.assert_array_equal(mine[k], ref[k], err_msg=k)
     assert mine["ray_stop_flag"] == ref["ray_stop_flag"]
+
+
+# ---- run_results.<label>.nc: the file's STRUCTURE against the reference writer ------------------------------------
+def _parse_classic_netcdf_header(path):
+    """NetCDF classic (CDF-1 / CDF-2) header, parsed from the bytes (no NetCDF library): dimensions in
+    definition order, global attributes, variables in definition order with type and dimension names."""
+    b = open(path, "rb").read()
+    assert b[:3] == b"CDF" and b[3] in (1, 2), "not a NetCDF classic file"
+    off64 = b[3] == 2
+    pos = 4
+
+    def u32():
+        nonlocal pos
+        v = struct.unpack_from(">I", b, pos)[0]
+        pos += 4
+        return v
+
+    def name():
+        nonlocal pos
+        n = u32()
+        s = b[pos:pos + n].decode()
+        pos += (n + 3) // 4 * 4
+        return s
+
+    TYPES = {1: "byte", 2: "char", 3: "short", 4: "int", 5: "float", 6: "double"}
+    SIZES = {1: 1, 2: 1, 3: 2, 4: 4, 5: 4, 6: 8}
+
+    def att_list():
+        nonlocal pos
+        tag, n = u32(), u32()
+        assert (tag, n) == (0, 0) or tag == 0x0C
+        out = {}
+        for _ in range(n):
+            k = name()
+            t, m = u32(), u32()
+            raw = b[pos:pos + m * SIZES[t]]
+            pos += (m * SIZES[t] + 3) // 4 * 4
+            out[k] = (TYPES[t], raw)
+        return out
+
+    numrecs = u32()
+    tag, n = u32(), u32()
+    assert tag == 0x0A
+    dims = []
+    for _ in range(n):
+        k = name()
+        dims.append((k, u32()))
+    gatts = att_list()
+    tag, n = u32(), u32()
+    assert tag == 0x0B
+    variables = []
+    for _ in range(n):
+        k = name()
+        nd = u32()
+        ids = [u32() for _ in range(nd)]
+        att_list()
+        t = u32()
+        u32()  # vsize
+        pos += 8 if off64 else 4  # begin
+        variables.append((k, TYPES[t], tuple(dims[i][0] for i in ids)))
+    return dict(numrecs=numrecs, dims=dims, gatts=gatts, vars=variables)
+
+
+def test_netcdf_file_structure_is_the_reference_writers(tmp_path):
+    """write_results_NC (ray_results_m.f90:171-249): dimension names, sizes and definition order (:205-209), variable
+    names, NetCDF types and dimension lists in definition order (:212-224; the Fortran dimension lists are
+    reversed in the file's C order), the global attribute (:227), max_number_of_points = maxval(npoints) (:202)."""
+    d = R.read_results_LD(REF_LD)
+    rr = _from_file(d)
+    path = str(tmp_path / "run_results.ld4.nc")
+    R.write_results_NC(path, rr)
+    h = _parse_classic_netcdf_header(path)
+    nray, npt, nv = 4, int(d["npoints"].max()), 7
+    assert h["numrecs"] == 0   # no unlimited dimension
+    assert h["dims"] == [("number_of_rays", nray), ("max_number_of_points", npt), ("dim_v_vector", nv), ("d8", 8),
+                         ("d60", 60)]
+    Rr, P, V = "number_of_rays", "max_number_of_points", "dim_v_vector"
+    assert h["vars"] == [
+        ("date_vector", "int", ("d8",)),
+        ("ray_vec", "double", (Rr, P, V)),              # Fortran [dim_v_vector, max_number_of_points, number_of_rays]
+        ("residual", "double", (Rr, P)),
+        ("npoints", "int", (Rr,)),
+        ("initial_ray_power", "float", (Rr,)),
+        ("ray_trace_time", "float", (Rr,)),
+        ("end_residuals", "float", (Rr,)),
+        ("max_residuals", "float", (Rr,)),
+        ("end_ray_parameter", "float", (Rr,)),
+        ("start_ray_vec", "float", (Rr, V)),
+        ("end_ray_vec", "float", (Rr, V)),
+        ("ray_stop_flag", "char", (Rr, "d60")),
+        ("total_trace_time", "float", ()),
+    ]
+    assert list(h["gatts"]) == ["RAYS_run_label"] and h["gatts"]["RAYS_run_label"][0] == "char"
+    assert h["gatts"]["RAYS_run_label"][1].decode().strip() == "ld4"
+    # and the payload, read back independently of the writer's own reader conventions
+    nc = R.read_results_NC(path)
+    np.testing.assert_array_equal(nc["ray_vec"], d["ray_vec"][:, :npt])
+    np.testing.assert_array_equal(nc["residual"], d["residual"][:, :npt])
+    np.testing.assert_array_equal(nc["end_ray_vec"], d["end_ray_vec"].astype(np.float32))
+    assert nc["ray_stop_flag"] == d["ray_stop_flag"]

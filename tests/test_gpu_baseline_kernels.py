@@ -204,3 +204,22 @@ def test_baseline_config_at_full_size_sampled_against_oracle(cfg, stride, kernel
     live = np.arange(p.nstep_max + 1)[None, :] < a.npoints[:, None]
     assert not a.ray_vec[~live].any() and not a.residual[~live].any()
     assert np.isfinite(a.ray_vec[live]).all()
+
+
+def test_trace_gather_device_resident_result():
+    """rays_hip_trace_gather: the library's own multi-GPU entry (blocks per device, RCCL gather to the root, result
+    left in device memory).  On the one-GPU box it runs with one device: the root traces into the global arrays and
+    no peer exists, so this covers the entry, the result block, its re-use across calls and rays_hip_result_to_host;
+    a repeated device in the list is refused (RCCL: one rank per device)."""
+    g, nml, p = load_golden("cfg2_solovev1024_rk4")
+    r0, n0 = g["rvec0_full"][:777], g["rindex_vec0_full"][:777]
+    ora = oracle_lib.trace(p, r0, n0)
+    hip.load().rays_hip_init(1)
+    for _ in range(2):
+        res, out = hip.trace_gather(p, r0, n0)
+        assert res.nray == 777 and res.device == 0 and res.ray_vec
+        _assert_same(out, ora)
+    hip.init_devices([0, 0])
+    with pytest.raises(hip.RaysHipError, match="must not repeat a device"):
+        hip.trace_gather(p, r0, n0)
+    hip.load().rays_hip_init(1)
