@@ -68,6 +68,9 @@ CASES = [
     # `neutrality` relaxed for that) and damping + integrate_eq_gradients (nv = 13)
     ("gold_slab_ns1_rk4", "gold_slab_ns1_rk4.in", None, 25, 60),
     ("gold_solovev64_damp_grad_rk4", "gold_solovev64_damp_grad_rk4.in", list(range(0, 64, 5)), 0, 0),
+    # more ion species: D + H + T + 3He + alpha (nspec = 5 -> NS = 6, SG) and D + T + 3He (NS = 4, RK4 numerical)
+    ("gold_slab_6spec_sg", "gold_slab_6spec_sg.in", None, 0, 0),
+    ("gold_solovev64_4spec_rk4_num", "gold_solovev64_4spec_rk4_num.in", list(range(0, 64, 5)), 0, 0),
 ]
 
 

@@ -32,6 +32,10 @@ static int run(int solver, int ns, int nv, const rays::DevParams& D, const rays:
   if constexpr ((EQ & 3) == 0) {
     if (ns == 1 && nv == 7) return run1<EQ, DERIV, 1, 7>(solver, D, A);
     if (ns == 3 && nv == 7) return run1<EQ, DERIV, 3, 7>(solver, D, A);
+    if (ns == 6 && nv == 7) return run1<EQ, DERIV, 6, 7>(solver, D, A);
+  }
+  if constexpr ((EQ & 3) == 1) {
+    if (ns == 4 && nv == 7) return run1<EQ, DERIV, 4, 7>(solver, D, A);
   }
   return 1;
 }
@@ -114,12 +118,17 @@ static bool emul_member(const rays::DevParams& D, const rays::FanArgs& F, const 
   if constexpr (EQ == 0) {
     if (D.nspec == 2) return rays::fan_member<EQ, 3>(D, F, rvec, ia, ib, ri);
     if (D.nspec == 0) return rays::fan_member<EQ, 1>(D, F, rvec, ia, ib, ri);
+    if (D.nspec == 5) return rays::fan_member<EQ, 6>(D, F, rvec, ia, ib, ri);
+  }
+  if constexpr (EQ == 1) {
+    if (D.nspec == 3) return rays::fan_member<EQ, 4>(D, F, rvec, ia, ib, ri);
   }
   return rays::fan_member<EQ, 2>(D, F, rvec, ia, ib, ri);
 }
 extern "C" int rays_emul_ray_init(const rays_params_t* p, const rays_fan_t* fan, int nray_max, double* rvec0,
                                   double* rindex_vec0, int32_t* nray) {
-  if (p->nspec != 1 && !((p->nspec == 2 || p->nspec == 0) && p->equilib_model == 0)) return 1;
+  if (p->nspec != 1 && !((p->nspec == 2 || p->nspec == 0 || p->nspec == 5) && p->equilib_model == 0) &&
+      !(p->nspec == 3 && p->equilib_model == 1)) return 1;
   rays::FanArgs F;
   std::vector<double> launch;
   int per_r = 0;
