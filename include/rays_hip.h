@@ -130,7 +130,8 @@ typedef struct rays_axisym_params {
 /* ---- everything trace_rays reads from module state ----------------------- */
 typedef struct rays_params {
   int32_t abi_version;  /* RAYS_ABI_VERSION */
-  int32_t nv;           /* ode_m.f90:160-173: 7, +1 with damping, +5 with integrate_eq_gradients */
+  int32_t nv;           /* ode_m.f90:160-173: 7, +1 with damping, +1+nspec with multi_spec_damping, +5 with
+                           integrate_eq_gradients */
   int32_t nspec;        /* species_m.f90:27 number of ion species (electrons are species 0) */
   int32_t nstep_max;    /* ode_m.f90:104 */
   int32_t ode_solver;   /* RAYS_ODE_* */
@@ -151,7 +152,7 @@ typedef struct rays_params {
   rays_solovev_params_t solovev;
   /* damping_m.f90:30-40 (appended in ABI version 2) */
   int32_t damping_model;      /* RAYS_DAMP_* */
-  int32_t multi_spec_damping; /* must be 0 on the device path */
+  int32_t multi_spec_damping; /* damping_m.f90:35: one absorbed-power row per species behind the total */
   double total_damping_limit; /* damping_m.f90:38 */
   /* appended in ABI version 3 */
   rays_axisym_params_t axisym;

@@ -999,6 +999,13 @@ static int eqn_ray(const rays_params_t* P, rf_ctx rf, const double* v, double* d
     damp_fund_ech(P, rf, &eq, v, vg, &ki);
     dvds[7] = dsd * 2. * ki * (1. - v[7]);
     nv0 = 8;
+    if (P->multi_spec_damping) { /* :207-212: ksi(0) = ki, ksi(1:nspec) = 0 (damp_fund_ECH.f90:122-124) */
+      for (int is = 0; is <= P->nspec; is++) {
+        const double ksi = is == 0 ? ki : 0.;
+        dvds[nv0 + is] = dsd * 2. * ksi * (1. - v[7]);
+      }
+      nv0 = nv0 + 1 + P->nspec;
+    }
   }
   if (P->integrate_eq_gradients) { /* :217-229 */
     for (int j = 0; j < 3; j++) {
@@ -1111,6 +1118,10 @@ static void initialize_ode_vector(const rays_params_t* P, rf_ctx rf, const doubl
   if (P->damping_model != RAYS_DAMP_NONE) {
     v[7] = 0.;
     nv0 = 8;
+    if (P->multi_spec_damping) { /* initialize_ode_vector.f90:36-39 */
+      for (int is = 0; is <= P->nspec; is++) v[8 + is] = 0.;
+      nv0 = nv0 + 1 + P->nspec;
+    }
   }
   if (P->integrate_eq_gradients) {
     eq_point eq;
@@ -1124,8 +1135,10 @@ static void initialize_ode_vector(const rays_params_t* P, rf_ctx rf, const doubl
 int rays_oracle_check_params(const rays_params_t* P) {
   if (P->abi_version != RAYS_ABI_VERSION) return 1;
   if (P->nspec < 0 || P->nspec > RAYS_NSPEC0) return 2;
-  if (P->nv != 7 + (P->damping_model ? 1 : 0) + (P->integrate_eq_gradients ? 5 : 0)) return 3;
-  if (P->multi_spec_damping) return 5;
+  if (P->multi_spec_damping && !P->damping_model) return 5; /* rows 9.. would never be set (eqn_ray.f90:196) */
+  if (P->nv != 7 + (P->damping_model ? 1 : 0) + (P->multi_spec_damping ? 1 + P->nspec : 0) +
+                   (P->integrate_eq_gradients ? 5 : 0))
+    return 3;
   if (P->damping_model == RAYS_DAMP_FUND_ECH && !zf_fspl) return 6;
   if (P->equilib_model == RAYS_EQ_AXISYM && (!AX.psi_fspl || !AX.rb_fspl)) return 7;
   if (P->nv > RAYS_ORACLE_NV_MAX) return 3;

@@ -4,7 +4,7 @@
 #define RAYS_ORACLE_H
 #include "../include/rays_hip.h"
 
-#define RAYS_ORACLE_NV_MAX 13
+#define RAYS_ORACLE_NV_MAX 19 /* 7 + 1 + (1 + nspec0) + 5: ode_m.f90:160-173 */
 
 #ifdef __cplusplus
 extern "C" {

@@ -25,8 +25,10 @@
 
 namespace rays {
 #define RAYS_DECL_ENTRIES(s, e, d) \
-  const KernelEntry* rays_entries_##s##_##e##_##d##_0(int* n); \
-  const KernelEntry* rays_entries_##s##_##e##_##d##_1(int* n);
+  const KernelEntry* rays_entries_##s##_##e##_##d##_0_0(int* n); \
+  const KernelEntry* rays_entries_##s##_##e##_##d##_1_0(int* n); \
+  const KernelEntry* rays_entries_##s##_##e##_##d##_0_1(int* n); \
+  const KernelEntry* rays_entries_##s##_##e##_##d##_1_1(int* n);
 RAYS_DECL_ENTRIES(0, 0, 0)
 RAYS_DECL_ENTRIES(0, 0, 1)
 RAYS_DECL_ENTRIES(0, 1, 0)
@@ -112,13 +114,16 @@ static_assert(rays::kBlock == rays::PointWindow<7>::kStride, "PointWindow rows a
 const rays::KernelEntry* find_kernel(const rays_params_t& p, long long nray = 0) {
   using namespace rays;
   typedef const KernelEntry* (*Getter)(int*);
-#define RAYS_G(s, e, d) {rays_entries_##s##_##e##_##d##_0, rays_entries_##s##_##e##_##d##_1}
-  static const Getter getters[2][3][2][2] = {
+  // [solver][equilibrium][derivative][unit exponents][multi_spec_damping]
+#define RAYS_G(s, e, d) {{rays_entries_##s##_##e##_##d##_0_0, rays_entries_##s##_##e##_##d##_0_1}, \
+                         {rays_entries_##s##_##e##_##d##_1_0, rays_entries_##s##_##e##_##d##_1_1}}
+  static const Getter getters[2][3][2][2][2] = {
       {{RAYS_G(0, 0, 0), RAYS_G(0, 0, 1)}, {RAYS_G(0, 1, 0), RAYS_G(0, 1, 1)}, {RAYS_G(0, 2, 0), RAYS_G(0, 2, 1)}},
       {{RAYS_G(1, 0, 0), RAYS_G(1, 0, 1)}, {RAYS_G(1, 1, 0), RAYS_G(1, 1, 1)}, {RAYS_G(1, 2, 0), RAYS_G(1, 2, 1)}}};
 #undef RAYS_G
   int n = 0;
-  const KernelEntry* e = getters[p.ode_solver][p.equilib_model][p.ray_deriv][unit_exponents(p) ? 1 : 0](&n);
+  const KernelEntry* e = getters[p.ode_solver][p.equilib_model][p.ray_deriv][unit_exponents(p) ? 1 : 0]
+                                [p.multi_spec_damping ? 1 : 0](&n);
   int ncu = 256;
   {
     int dev = 0;
@@ -418,9 +423,12 @@ int rays_hip_check_params(const rays_params_t* p) {
     return fail("equilibrium_m: invalid equilibrium model (device path: slab | solovev | axisym_toroid)");
   if (p->damping_model != RAYS_DAMP_NONE && p->damping_model != RAYS_DAMP_FUND_ECH)
     return fail("damping: Unimplemented damping model");  // damping_m.f90:103-106
-  if (p->multi_spec_damping) return fail("rays_hip: multi_spec_damping is not on the device path");
-  if (p->nv != 7 + (p->damping_model ? 1 : 0) + (p->integrate_eq_gradients ? 5 : 0))
-    return fail("rays_hip: nv must be 7 (+1 with damping, +5 with integrate_eq_gradients) (ode_m.f90:160-173)");
+  if (p->multi_spec_damping && !p->damping_model)  // eqn_ray.f90:196-213: the species rows sit inside the damping branch
+    return fail("rays_hip: multi_spec_damping without a damping model leaves its rows of the ODE vector undefined");
+  if (p->nv != 7 + (p->damping_model ? 1 : 0) + (p->multi_spec_damping ? 1 + p->nspec : 0) +
+                   (p->integrate_eq_gradients ? 5 : 0))
+    return fail("rays_hip: nv must be 7 (+1 with damping, +1+nspec with multi_spec_damping, +5 with "
+                "integrate_eq_gradients) (ode_m.f90:160-173)");
   if (p->nstep_max < 0) return fail("rays_hip: nstep_max < 0");
   if (p->equilib_model == RAYS_EQ_SOLOVEV) {
     if (p->solovev.dens_prof_model != RAYS_SOLOVEV_N_CONSTANT && p->solovev.dens_prof_model != RAYS_SOLOVEV_N_PARABOLIC)

@@ -138,6 +138,19 @@ RAYS_DEV double pow4(double x) { return ((x * x) * x) * x; }  // flang lowers x*
 // spills in the hot loop.
 // The template argument EQ of the kernels carries the flag: EQ = model | (UE ? kEqUnitExp : 0).
 constexpr int kEqUnitExp = 4;
+// multi_spec_damping (damping_m.f90:35, ode_m.f90:169): one absorbed-power row per species behind the total.
+// Carried in EQ as well, because nv alone is ambiguous (nv = 12 is integrate_eq_gradients without damping, or
+// damping + four species' rows; nv = 13 likewise).
+constexpr int kEqMultiSpec = 8;
+// Layout of the ODE vector (ode_m.f90:160-173, initialize_ode_vector.f90:25-54):
+//   v(1:6) = (r, k), v(7) = s, [v(8) = total absorbed power, [v(9:9+nspec) per species]], [5 gradient rows]
+template <bool MULTI, int NS, int NV>
+struct RayVec {
+  static constexpr bool DAMP = MULTI || NV == 8 || NV == 13;
+  static constexpr int NV0 = 7 + (DAMP ? 1 : 0) + (MULTI ? NS : 0);  // rows before the gradient block
+  static constexpr bool GRAD = NV == NV0 + 5;
+  static_assert(NV == NV0 || NV == NV0 + 5, "nv does not match the damping / gradient options");
+};
 template <bool UE, bool Y1>
 RAYS_DEV double pow_u(double x, double y) {
   if (UE) return Y1 ? x : 1.0;
@@ -1081,7 +1094,7 @@ RAYS_DEV double damp_fund_ech(const DevParams& P, const EqPoint<NS>& eq, const d
 // eqn_ray tail               eqn_ray.f90:131-229: group velocity + ray equations from dD/d(x,k,w).
 // Returns a stop code (0 = ok).  NV = 7 (+5 with integrate_eq_gradients).
 // ---------------------------------------------------------------------------------------------
-template <int NS, int NV>
+template <int NS, int NV, bool MULTI = false>
 RAYS_DEV int ray_equations(const DevParams& P, const EqPoint<NS>& eq, const double kvec[3], double v7,
                            const double dddx[3], const double dddk[3], double dddw, double dvds[NV]) {
   if (!(dddw != 0.)) return RAYS_STOP_INFINITE_VG_RHS;  // :133 (`/= 0.` is true for NaN)
@@ -1113,13 +1126,18 @@ RAYS_DEV int ray_equations(const DevParams& P, const EqPoint<NS>& eq, const doub
     dsd = vg0;
   }
   dvds[6] = dsd;  // :190
-  constexpr bool DAMP = (NV == 8 || NV == 13);
-  constexpr int NV0 = DAMP ? 8 : 7;
+  typedef RayVec<MULTI, NS, NV> L;
+  constexpr bool DAMP = L::DAMP;
+  constexpr int NV0 = L::NV0;
   if (DAMP) {  // :196-204
     const double ki = damp_fund_ech<NS>(P, eq, kvec, vg);
     dvds[7] = dsd * 2. * ki * (1. - v7);
+    if (MULTI) {  // :207-212: ksi(0) = ki, ksi(1:nspec) = 0 (damp_fund_ECH.f90:122-124)
+#pragma unroll
+      for (int is = 0; is < NS; is++) dvds[8 + is] = dsd * 2. * (is == 0 ? ki : 0.) * (1. - v7);
+    }
   }
-  if (NV >= 12) {  // :217-229 integrate_eq_gradients
+  if (L::GRAD) {  // :217-229 integrate_eq_gradients
     const Recip Rvg0 = make_recip(vg0);
     double vu[3];
 #pragma unroll
@@ -1148,7 +1166,8 @@ RAYS_DEV int eqn_ray(const DevParams& P, const double v[NV], double dvds[NV]) {
   } else {
     deriv_num<EQ, NS>(P, eq, rvec, kvec, dddx, dddk, dddw);
   }
-  return ray_equations<NS, NV>(P, eq, kvec, v[NV > 7 ? 7 : 0], dddx, dddk, dddw, dvds);
+  constexpr bool MULTI = (EQ & kEqMultiSpec) != 0;
+  return ray_equations<NS, NV, MULTI>(P, eq, kvec, v[RayVec<MULTI, NS, NV>::DAMP ? 7 : 0], dddx, dddk, dddw, dvds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1206,14 +1225,16 @@ RAYS_DEV void rhs_eval(const DevParams& P, const double v[NV], bool do_check, do
       cs_flag = RAYS_STOP_INFINITE_VG_CHECK;  // :107-108
     }
   }
-  if (do_check && (NV == 8 || NV == 13)) {  // check_save.f90:114-125
-    if (v[NV > 7 ? 7 : 0] > P.total_damping_limit) {
+  constexpr bool MULTI = (EQ & kEqMultiSpec) != 0;
+  constexpr bool DAMP = RayVec<MULTI, NS, NV>::DAMP;
+  if (do_check && DAMP) {  // check_save.f90:114-125
+    if (v[DAMP ? 7 : 0] > P.total_damping_limit) {
       cs_stop = true;
       cs_flag = RAYS_STOP_TOTAL_ABSORPTION;
     }
   }
   if (DERIV == RAYS_DERIV_NUM) deriv_num<EQ, NS>(P, eq, rvec, kvec, dddx, dddk, dddw);
-  const int rc = ray_equations<NS, NV>(P, eq, kvec, v[NV > 7 ? 7 : 0], dddx, dddk, dddw, f);
+  const int rc = ray_equations<NS, NV, MULTI>(P, eq, kvec, v[DAMP ? 7 : 0], dddx, dddk, dddw, f);
   code = eq.err ? eq.err : rc;  // eqn_ray.f90:90-102 returns before the derivatives
 }
 
@@ -1227,10 +1248,11 @@ RAYS_DEV void initialize_ode_vector(const DevParams& P, const double* __restrict
     v[3 + i] = P.k0 * n0[i];
   }
   v[6] = 0.;
-  constexpr bool DAMP = (NV == 8 || NV == 13);
-  constexpr int NV0 = DAMP ? 8 : 7;
-  if (DAMP) v[7] = 0.;
-  if (NV >= 12) {
+  typedef RayVec<(EQ & kEqMultiSpec) != 0, NS, NV> L;
+  constexpr int NV0 = L::NV0;
+#pragma unroll
+  for (int i = 7; i < NV0; i++) v[i] = 0.;  // total absorbed power (+ one row per species)
+  if (L::GRAD) {
     EqPoint<NS> eq;
     const double rvec[3] = {v[0], v[1], v[2]};
     equilibrium<EQ, NS>(P, const_recip(P.omgrf, P.inv_omgrf), const_recip(P.omgrf2, P.inv_omgrf2), rvec, eq, false);

@@ -1,8 +1,10 @@
 // rays_inst.hip -- kernel instantiations.  Compiled once per (solver, equilibrium, derivative,
 // unit-exponent) group:
-//   -DRAYS_INST_SOLVER={0,1} -DRAYS_INST_EQ={0,1,2} -DRAYS_INST_DERIV={0,1} -DRAYS_INST_UE={0,1}
+//   -DRAYS_INST_SOLVER={0,1} -DRAYS_INST_EQ={0,1,2} -DRAYS_INST_DERIV={0,1} -DRAYS_INST_UE={0,1} -DRAYS_INST_MS={0,1}
+//   -DRAYS_INST_EQT=<EQ + 4 UE + 8 MS>  (the kernels' EQ template argument as a literal, for the kernel names)
 // Each group instantiates the species counts NS = 1..6 (nspec = 0..5, species_m.f90:25) and
-// nv = 7 | 12 (integrate_eq_gradients) and 8 | 13 (+ damping) (ode_m.f90:160-173).
+// nv = 7 | 12 (integrate_eq_gradients) and 8 | 13 (+ damping) (ode_m.f90:160-173); the MS = 1 groups
+// (multi_spec_damping) nv = 8 + NS | 13 + NS.
 #include "rays_launch.hpp"
 #if RAYS_INST_SOLVER == 0
 #include "rays_rk4.hpp"
@@ -10,17 +12,14 @@
 #include "rays_sg.hpp"
 #endif
 
-#define RAYS_CAT_(a, b, c, d, e) a##_##b##_##c##_##d##_##e
-#define RAYS_CAT(a, b, c, d, e) RAYS_CAT_(a, b, c, d, e)
+#ifndef RAYS_INST_MS
+#define RAYS_INST_MS 0
+#endif
+#define RAYS_CAT_(a, b, c, d, e, f) a##_##b##_##c##_##d##_##e##_##f
+#define RAYS_CAT(a, b, c, d, e, f) RAYS_CAT_(a, b, c, d, e, f)
 // the kernels' EQ template argument, as a literal (it appears in the kernel names rocprof prints)
-#if !RAYS_INST_UE
-#define RAYS_INST_EQT RAYS_INST_EQ
-#elif RAYS_INST_EQ == 0
-#define RAYS_INST_EQT 4
-#elif RAYS_INST_EQ == 1
-#define RAYS_INST_EQT 5
-#else
-#define RAYS_INST_EQT 6
+#ifndef RAYS_INST_EQT
+#error "pass -DRAYS_INST_EQT=<RAYS_INST_EQ + 4 RAYS_INST_UE + 8 RAYS_INST_MS>"
 #endif
 #define RAYS_STR_(x) #x
 #define RAYS_STR(x) RAYS_STR_(x)
@@ -29,7 +28,7 @@ namespace rays {
 
 namespace {
 constexpr int EQ = RAYS_INST_EQT;
-static_assert(EQ == (RAYS_INST_EQ | (RAYS_INST_UE ? kEqUnitExp : 0)), "EQ encoding");
+static_assert(EQ == (RAYS_INST_EQ | (RAYS_INST_UE ? kEqUnitExp : 0) | (RAYS_INST_MS ? kEqMultiSpec : 0)), "EQ encoding");
 constexpr int DERIV = RAYS_INST_DERIV;
 
 template <int NS, int NV, int OCC = 1>
@@ -70,7 +69,15 @@ hipError_t launch_one(const DevParams& P, const TraceArgs& A, hipStream_t stream
   { RAYS_INST_SOLVER, EQ, NS, DERIV, NV, 2, 0, "rk4_trace_kernel_w2<" RAYS_STR(RAYS_INST_EQT) ", " #NS ", " RAYS_STR(RAYS_INST_DERIV) ", " #NV ">", &launch_one<NS, NV, 2> }
 
 const KernelEntry kEntries[] = {
-#ifdef RAYS_INST_FAST  // developer builds (make FAST=1): electrons + one ion species only
+#if RAYS_INST_MS
+    // multi_spec_damping: nv = 7 + 1 + (1 + nspec) (+ 5 with integrate_eq_gradients), ode_m.f90:160-173
+#ifdef RAYS_INST_FAST
+    RAYS_ENTRY(2, 10), RAYS_ENTRY(2, 15),
+#else
+    RAYS_ENTRY(1, 9), RAYS_ENTRY(2, 10), RAYS_ENTRY(3, 11), RAYS_ENTRY(4, 12), RAYS_ENTRY(5, 13), RAYS_ENTRY(6, 14),
+    RAYS_ENTRY(1, 14), RAYS_ENTRY(2, 15), RAYS_ENTRY(3, 16), RAYS_ENTRY(4, 17), RAYS_ENTRY(5, 18), RAYS_ENTRY(6, 19),
+#endif
+#elif defined(RAYS_INST_FAST)  // developer builds (make FAST=1): electrons + one ion species only
     RAYS_ENTRY(2, 7), RAYS_ENTRY(2, 8),
 #if RAYS_INST_SOLVER == 0 && RAYS_INST_EQ != 2
     RAYS_ENTRY_OCC2(2, 7),
@@ -92,7 +99,7 @@ const KernelEntry kEntries[] = {
 
 #if defined(RAYS_SG_PROFILE) && RAYS_INST_SOLVER == 1
 // developer builds only: per-section wave clocks of this group's SG kernels
-extern "C" int RAYS_CAT(rays_debug_sg_profile, RAYS_INST_SOLVER, RAYS_INST_EQ, RAYS_INST_DERIV, RAYS_INST_UE)(unsigned long long* out, int reset) {
+extern "C" int RAYS_CAT(rays_debug_sg_profile, RAYS_INST_SOLVER, RAYS_INST_EQ, RAYS_INST_DERIV, RAYS_INST_UE, RAYS_INST_MS)(unsigned long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sg_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
   if (reset) {
     unsigned long long z[16] = {0};
@@ -102,7 +109,7 @@ extern "C" int RAYS_CAT(rays_debug_sg_profile, RAYS_INST_SOLVER, RAYS_INST_EQ, R
 }
 #endif
 
-const KernelEntry* RAYS_CAT(rays_entries, RAYS_INST_SOLVER, RAYS_INST_EQ, RAYS_INST_DERIV, RAYS_INST_UE)(int* n) {
+const KernelEntry* RAYS_CAT(rays_entries, RAYS_INST_SOLVER, RAYS_INST_EQ, RAYS_INST_DERIV, RAYS_INST_UE, RAYS_INST_MS)(int* n) {
   *n = (int)(sizeof(kEntries) / sizeof(kEntries[0]));
   return kEntries;
 }

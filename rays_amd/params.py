@@ -303,8 +303,9 @@ def params_from_namelist(nml: Dict[str, Dict[str, Any]], axisym_tables: Dict[str
     # ---- damping_m.f90:46-68 ---------------------------------------------------------------
     p.damping_model = _lookup(DAMPING, damp.get("damping_model", "no_damp"), "damping model")
     p.multi_spec_damping = 1 if bool(damp.get("multi_spec_damping", False)) else 0
-    if p.multi_spec_damping:
-        raise ConfigError("multi_spec_damping is not on the device path yet")
+    if p.multi_spec_damping and not p.damping_model:
+        # nv would grow by 1 + nspec rows that eqn_ray never sets (eqn_ray.f90:196-213 is inside the damping branch)
+        raise ConfigError("multi_spec_damping needs a damping model (damping_model = 'no_damp' leaves its rows undefined)")
     p.total_damping_limit = float(damp.get("total_damping_limit", _f32(0.99)))
 
     # ---- equilibrium ---------------------------------------------------------------------
@@ -373,7 +374,8 @@ def params_from_namelist(nml: Dict[str, Dict[str, Any]], axisym_tables: Dict[str
     p.s_max = float(ode.get("s_max", 0.0))
     p.ds = float(ode.get("ds", 0.0))
     p.integrate_eq_gradients = 1 if bool(diag.get("integrate_eq_gradients", False)) else 0
-    p.nv = 7 + (1 if p.damping_model else 0) + (5 if p.integrate_eq_gradients else 0)  # ode_m.f90:160-173
+    p.nv = (7 + (1 if p.damping_model else 0) + (1 + p.nspec if p.multi_spec_damping else 0)
+            + (5 if p.integrate_eq_gradients else 0))  # ode_m.f90:160-173
     p.rel_err0 = float(sg.get("rel_err0", 0.0))
     p.abs_err0 = float(sg.get("abs_err0", 0.0))
     p.SG_error_limit = float(sg.get("sg_error_limit", _f32(0.1)))

@@ -16,7 +16,8 @@ GOLDEN_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_n
                 "gold_solovev64_damp_rk4", "gold_solovev64_damp_sg", "gold_axisym64_eqdsk_damp_rk4",
                 "gold_axisym64_eqdsk_damp_sg", "gold_axisym64_eqdsk_tspline_rk4_num", "gold_axisym16_eqdsk_zexit_rk4",
                 "gold_slab_toroid_parab_arcl_grad_rk4", "gold_slab_shear_gauss_3spec_sg_num", "gold_slab_lin2_rk4_num",
-                "gold_slab_ns1_rk4", "gold_solovev64_damp_grad_rk4", "gold_slab_6spec_sg", "gold_solovev64_4spec_rk4_num"]
+                "gold_slab_ns1_rk4", "gold_solovev64_damp_grad_rk4", "gold_slab_6spec_sg", "gold_solovev64_4spec_rk4_num",
+                "gold_solovev64_damp_multi_sg", "gold_slab16_damp_multi_grad_rk4"]
 
 
 def load_golden(name):

@@ -71,6 +71,9 @@ CASES = [
     # more ion species: D + H + T + 3He + alpha (nspec = 5 -> NS = 6, SG) and D + T + 3He (NS = 4, RK4 numerical)
     ("gold_slab_6spec_sg", "gold_slab_6spec_sg.in", None, 0, 0),
     ("gold_solovev64_4spec_rk4_num", "gold_solovev64_4spec_rk4_num.in", list(range(0, 64, 5)), 0, 0),
+    # multi_spec_damping: one absorbed-power row per species behind the total (nv = 10 | 15; ode_m.f90:169)
+    ("gold_solovev64_damp_multi_sg", "gold_solovev64_damp_multi_sg.in", list(range(0, 64, 5)), 0, 0),
+    ("gold_slab16_damp_multi_grad_rk4", "gold_slab16_damp_multi_grad_rk4.in", None, 0, 0),
 ]
 
 

@@ -39,6 +39,17 @@ static int run(int solver, int ns, int nv, const rays::DevParams& D, const rays:
   }
   return 1;
 }
+// multi_spec_damping kernels (EQ | kEqMultiSpec): Solovev nv = 10, slab nv = 15 (two species)
+template <int EQ, int DERIV>
+static int run_ms(int solver, int ns, int nv, const rays::DevParams& D, const rays::TraceArgs& A) {
+  if constexpr ((EQ & 3) == 1) {
+    if (ns == 2 && nv == 10) return run1<EQ, DERIV, 2, 10>(solver, D, A);
+  }
+  if constexpr ((EQ & 3) == 0) {
+    if (ns == 2 && nv == 15) return run1<EQ, DERIV, 2, 15>(solver, D, A);
+  }
+  return 1;
+}
 
 static std::vector<double> g_zfun;
 static int g_zf_nx = 0;
@@ -103,8 +114,13 @@ extern "C" int rays_emul_trace_ex(const rays_params_t* p, int nray, const double
   }
   // same kernel selection as rays_capi.hip: find_kernel (EQ = model | kEqUnitExp)
   const int e = p->equilib_model | (unit_exponents(*p) ? rays::kEqUnitExp : 0), d = p->ray_deriv, s = p->ode_solver;
-#define RAYS_EMUL_CASE(E, D) if (e == E && d == D) return run<E, D>(s, p->nspec + 1, p->nv, D_, A); else
   const rays::DevParams& D_ = D;
+  if (p->multi_spec_damping) {
+    if (e == 5 && d == 0) return run_ms<5 | rays::kEqMultiSpec, 0>(s, p->nspec + 1, p->nv, D_, A);
+    if (e == 4 && d == 0) return run_ms<4 | rays::kEqMultiSpec, 0>(s, p->nspec + 1, p->nv, D_, A);
+    return 4;
+  }
+#define RAYS_EMUL_CASE(E, D) if (e == E && d == D) return run<E, D>(s, p->nspec + 1, p->nv, D_, A); else
   RAYS_EMUL_CASE(0, 0) RAYS_EMUL_CASE(0, 1) RAYS_EMUL_CASE(1, 0) RAYS_EMUL_CASE(1, 1) RAYS_EMUL_CASE(2, 0) RAYS_EMUL_CASE(2, 1)
   RAYS_EMUL_CASE(4, 0) RAYS_EMUL_CASE(4, 1) RAYS_EMUL_CASE(5, 0) RAYS_EMUL_CASE(5, 1) RAYS_EMUL_CASE(6, 0) RAYS_EMUL_CASE(6, 1)
   return 4;

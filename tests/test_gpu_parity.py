@@ -20,10 +20,11 @@ RK4_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_num"
              "gold_axisym64_eqdsk_tspline_rk4_num", "gold_slab16_fast_rk4",
              "gold_slab_box_exits_rk4", "gold_slab_negative_temp_rk4", "gold_axisym16_eqdsk_zexit_rk4",
              "gold_slab_negative_dens_rk4", "gold_slab16_damp_rk4",
-             "gold_slab_ns1_rk4", "gold_solovev64_damp_grad_rk4", "gold_solovev64_4spec_rk4_num"]
+             "gold_slab_ns1_rk4", "gold_solovev64_damp_grad_rk4", "gold_solovev64_4spec_rk4_num",
+             "gold_slab16_damp_multi_grad_rk4"]
 SG_CASES = ["gold_solovev64_sg_cold", "gold_solovev64_sg_num", "gold_solovev64_damp_sg", "gold_axisym64_eqdsk_damp_sg",
             "gold_solovev64_arcl_grad_sg", "gold_solovev64_slow_sg",
-            "gold_slab_shear_gauss_3spec_sg_num", "gold_slab_6spec_sg"]
+            "gold_slab_shear_gauss_3spec_sg_num", "gold_slab_6spec_sg", "gold_solovev64_damp_multi_sg"]
 
 @pytest.mark.parametrize("name", RK4_CASES)
 def test_rk4_matches_reference_golden(name):

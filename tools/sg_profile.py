@@ -9,8 +9,8 @@ from rays_amd.trace import DeviceTrace
 NAMES = ["loop/refill", "init+vote", "RHS", "CHECK bookkeeping", "AFTER_F2", "AFTER_F3", "CRASH", "DE_BEGIN",
          "DE_TOP", "START_DONE", "COEF tail", "STOP+tail", "COEF coefficient block", "COEF scale+shift",
          "COEF predictor", "RHS, <= 8 lanes served"]
-for cfg, sym in (("configs/cfg5_axisym256k_sg_damp.in", "rays_debug_sg_profile_1_2_0_1"),
-                 ("configs/cfg3_solovev64k_sg_num.in", "rays_debug_sg_profile_1_1_1_1")):
+for cfg, sym in (("configs/cfg5_axisym256k_sg_damp.in", "rays_debug_sg_profile_1_2_0_1_0"),
+                 ("configs/cfg3_solovev64k_sg_num.in", "rays_debug_sg_profile_1_1_1_1_0")):
     nml, p, r0, n0 = bench.build_fan(cfg, 1)
     dt = DeviceTrace(p, r0, n0)
     fn = getattr(hip.load(), sym); fn.restype = C.c_int
