@@ -184,10 +184,9 @@ struct SgPhi {
   // the workspace behind rows .. 14: one read and one write of each per step, issued well ahead of their use;
   // LDS is worth more as phi rows (measurements at RAYS_SG_TIER above).
   RAYS_DEV double* rnd_col() const { return sg_far_column(*args) + (SgCoef::kFarDoubles + kFarDoubles) * sg_far_stride(); }
-  RAYS_DEV double rnd15(int l) const { return rnd_col()[l * sg_far_stride()]; }
-  RAYS_DEV double rnd16(int l) const { return rnd_col()[(NV + l) * sg_far_stride()]; }
-  RAYS_DEV void set_rnd15(int l, double x) const { rnd_col()[l * sg_far_stride()] = x; }
-  RAYS_DEV void set_rnd16(int l, double x) const { rnd_col()[(NV + l) * sg_far_stride()] = x; }
+  // (take rnd_col() ONCE per block of accesses: it re-reads the workspace pointer from the kernel arguments)
+  RAYS_DEV static double& rnd15(double* col, int l) { return col[l * sg_far_stride()]; }
+  RAYS_DEV static double& rnd16(double* col, int l) { return col[(NV + l) * sg_far_stride()]; }
   const TraceArgs* args;  // rows R+LR+1..14: global workspace behind the coefficient tiers (see SgCoef)
   static constexpr int kFarRows = 14 - R - LR;
   static constexpr int kFarDoubles = kFarRows * NV;
@@ -405,6 +404,11 @@ RAYS_DEV double gstr(int i) {
   return r;
 }
 
+#ifndef RAYS_SG_PATIENCE
+#define RAYS_SG_PATIENCE 128
+#endif
+constexpr int kSgPatienceMax = RAYS_SG_PATIENCE, kSgPatienceProbe = 16, kSgProbeTrips = 512;
+
 template <int EQ, int NS, int DERIV, int NV>
 __global__ void __launch_bounds__(256)
 sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
@@ -450,6 +454,8 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
   double p5eps = 0., round_ = 0., xold = 0., absh = 0., erk = 0., erkm1 = 0.;
   int k = 1, kold = 0, ns = 0, knew = 1, ifail = 0, nostep = 0, kle4 = 0;
   int resume = SEG_WAIT;  // continuation segment deferred to the next trip (the rare DE_TOP -> CRASH edge)
+  int waited = 0;         // trips this lane has waited at PC_CHECK for the rest of its wave (interval alignment)
+  int patience = kSgPatienceMax, probe = 0;  // wave-uniform: see "Interval alignment" below
   // Per-lane logicals are kept as bits of ONE integer VGPR rather than as `bool`s: a bool that is
   // live across the divergent continuation loop is a 64-bit lane mask in SGPRs, and with ~10 of
   // them the register allocator spills lane masks inside divergent control flow.
@@ -490,9 +496,38 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
     // a lane idles about once per output interval (an interval has an odd number of evaluations).
     const bool in_f2 = pc == PC_F2;
     const bool wants_rhs = alive && resume == SEG_WAIT;  // a lane with a deferred segment needs no evaluation
-    const int n_f2 = __popcll(__ballot(wants_rhs && in_f2)), n_other = __popcll(__ballot(wants_rhs && !in_f2));
-    const bool serve_f2 = n_f2 > n_other;
-    const bool act = wants_rhs && (in_f2 == serve_f2);
+    // Interval alignment.  A lane that has completed its output interval (PC_CHECK) waits until no lane of the
+    // wave is inside an interval any more; then ONE trip serves all of them, so check_save's extra work in the RHS
+    // and the once-per-interval segments (CHECK, DE_BEGIN, intrp, START_DONE) run once per interval for the wave
+    // instead of on nearly every trip for one or two lanes.  Where a lane's interval needs many more evaluations
+    // than its neighbours' (step-size thrashing at noise-level tolerances: the Solovev fan with finite-difference
+    // dD) waiting would cost more than it saves, so the wave has a PATIENCE: the longest wait it accepts, halved
+    // each time it runs out, raised again by alignments that complete; at zero the wave uses the plain two-phase
+    // vote (CHECK lanes ride with the corrector phase) and probes again after a while.  Measured (cfg 5 | cfg 3, ms):
+    // no alignment 109.7 | 324; fixed patience 4: 114.9 | 348, 32: 103.2 | 306, 64: 95.6 | 342, 128: 93.8 | 433,
+    // unbounded: 95.5 | 1199; adaptive with maximum 32: 101.1 | 302.7, 64: 96.0 | 304.1, 128: 93.9 | 296.6.
+    const bool at_check = pc == PC_CHECK;
+    bool act;
+    if (patience > 0) {
+      const int n_f2 = __popcll(__ballot(wants_rhs && in_f2));
+      const int n_f3 = __popcll(__ballot(wants_rhs && !in_f2 && !at_check));
+      const bool all_arrived = n_f2 + n_f3 == 0;
+      const bool timed_out = !all_arrived && __any(wants_rhs && at_check && waited >= patience);
+      const bool serve_check = all_arrived || timed_out;
+      const bool serve_f2 = n_f2 > n_f3;
+      act = wants_rhs && (serve_check ? at_check : (!at_check && in_f2 == serve_f2));
+      waited = (wants_rhs && at_check && !serve_check) ? waited + 1 : 0;
+      if (timed_out) patience = patience / 2;                             // wave-uniform: every lane computes the same
+      else if (all_arrived) patience = patience + 8 < kSgPatienceMax ? patience + 8 : kSgPatienceMax;
+      probe = 0;
+    } else {
+      const int n_f2 = __popcll(__ballot(wants_rhs && in_f2)), n_other = __popcll(__ballot(wants_rhs && !in_f2));
+      const bool serve_f2 = n_f2 > n_other;
+      act = wants_rhs && (in_f2 == serve_f2);
+      waited = 0;
+      probe = probe + 1;
+      if (probe >= kSgProbeTrips) patience = kSgPatienceProbe;
+    }
     // RHS input: the recorded state (PC_CHECK), the predicted p (PC_F2), else the current yy
     double win[NV];
 #pragma unroll
@@ -619,11 +654,12 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
               hold = h;
               const double hg = h * S.g(kp1);
               if (!(fl & FL_NORND)) {
+                double* const rnd = F.rnd_col();
 #pragma unroll
                 for (int l = 0; l < NV; l++) {
-                  const double rho = hg * (f[l] - F.lo[0][l]) - F.rnd16(l);
+                  const double rho = hg * (f[l] - F.lo[0][l]) - F.rnd16(rnd, l);
                   yy[l] = pp[l] + rho;
-                  F.set_rnd15(l, (yy[l] - pp[l]) - rho);
+                  F.rnd15(rnd, l) = (yy[l] - pp[l]) - rho;
                 }
               } else {
 #pragma unroll
@@ -869,8 +905,9 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
             fl |= FL_NORND;
             if (p5eps <= 100.0 * round_) {
               fl &= ~FL_NORND;
+              double* const rnd = F.rnd_col();
 #pragma unroll
-              for (int l = 0; l < NV; l++) F.set_rnd15(l, 0.0);
+              for (int l = 0; l < NV; l++) F.rnd15(rnd, l) = 0.0;
             }
             ifail = 0;
             seg = SEG_COEF;
@@ -962,11 +999,12 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
           F.predict(k, [&](int i) { return S.g(i); }, pp);
           SG_PROF(14);  // predictor
           if (!(fl & FL_NORND)) {
+            double* const rnd = F.rnd_col();
 #pragma unroll
             for (int l = 0; l < NV; l++) {
-              const double tau = h * pp[l] - F.rnd15(l);
+              const double tau = h * pp[l] - F.rnd15(rnd, l);
               pp[l] = yy[l] + tau;
-              F.set_rnd16(l, (pp[l] - yy[l]) - tau);
+              F.rnd16(rnd, l) = (pp[l] - yy[l]) - tau;
             }
           } else {
 #pragma unroll
