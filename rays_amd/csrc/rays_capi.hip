@@ -209,6 +209,7 @@ int get_axisym_device(rays::DevParams* D) {
   D->a_ti_grid = b + g_axi.off[9]; D->a_ti_fspl = b + g_axi.off[10];
   D->a_tab1d_doubles = (int)(g_axi.blob.size() - g_axi.off[3]);  // rb .. ti: contiguous at the end of the blob
   D->a_lds_tab = 0;
+  D->a_lds_rz = 0;
   return 0;
 }
 

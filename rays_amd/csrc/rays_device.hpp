@@ -38,6 +38,8 @@ struct DevParams {
   int damping_model, zf_nx;                 // damping_m.f90:30-40; Z-function spline grid size
   double total_damping_limit, zf_xmin, zf_xmax;
   const double* zf_fspl;                    // device pointer: fsplRe[nx][4] (zfunctions_m.f90)
+  unsigned zf_lds;                          // LDS byte address of a staged copy of fsplRe (0 = none): the lookup sits
+                                            // at the very end of the RHS' dependency chain, nothing hides its latency
   // axisym_toroid + eqdsk spline magnetics (axisym_toroid_eq_m.f90, eqdsk_magnetics_spline_interp_m.f90)
   int a_n_model, a_nr, a_nz, a_n_rb, a_n_ne, a_n_te, a_n_ti;
   int a_t_model[RAYS_NS0];
@@ -52,6 +54,9 @@ struct DevParams {
   // of two dependent trips to L2 per evaluation of the equilibrium.
   int a_tab1d_doubles;
   unsigned a_lds_tab;
+  // likewise the two grids of the bicubic psi spline (r_grid then z_grid, 2 x ~65 doubles): the cell search reads
+  // x(i-1), x(i) twice in a row, each a dependent trip to L2 otherwise
+  unsigned a_lds_rz;
   double ds, s_max, omgrf, k0, clight, eps0, resid_limit;
   double omgrf2;               // omgrf**2                      equilibrium_m.f90:264
   double two_over_k0;          // 2./k0                         deriv_cold.f90:51
@@ -501,8 +506,18 @@ RAYS_DEV void spl1_fp(PTR grid, PTR fspl, int n, double x, double& f, double& fp
 // eval_2D_fpp: f, fx, fy, fxx, fxy, fyy (quick_cube_splines_m.f90:305-332, bcspevfn ict = 1,1,1,1,1,1)
 RAYS_DEV void spl2_fpp(const DevParams& P, double x, double y, double out[6]) {
   double dx, dy;
-  const int i = spl_cell<const double*>(P.a_r_grid, P.a_nr, x, dx);
-  const int j = spl_cell<const double*>(P.a_z_grid, P.a_nz, y, dy);
+  int i, j;
+#ifndef RAYS_HOST_EMUL
+  if (P.a_lds_rz) {  // wave-uniform
+    const eq_lds_ptr rg = (eq_lds_ptr)(unsigned long long)P.a_lds_rz;
+    i = spl_cell<eq_lds_ptr>(rg, P.a_nr, x, dx);
+    j = spl_cell<eq_lds_ptr>(rg + P.a_nr, P.a_nz, y, dy);
+  } else
+#endif
+  {
+    i = spl_cell<const double*>(P.a_r_grid, P.a_nr, x, dx);
+    j = spl_cell<const double*>(P.a_z_grid, P.a_nz, y, dy);
+  }
   const double* c = P.a_psi_fspl + 16 * ((long long)(i - 1) + (long long)P.a_nr * (long long)(j - 1));
   double F[4][4];  // F[a-1][b-1] = f(a,b,i,j)
 #pragma unroll
@@ -1017,8 +1032,18 @@ RAYS_DEV Cplx zfun_real_arg_spline(const DevParams& P, double z) {
     else if (z > zf_x(P, i + 1)) i = i + 1;
     i = i < 1 ? 1 : (i > nxm ? nxm : i);
     const double dx = z - zf_x(P, i);
-    const double* f = P.zf_fspl + 4 * (long long)(i - 1);
-    re = f[0] + dx * (f[1] + dx * (f[2] + dx * f[3]));
+    double f0, f1, f2, f3;
+#ifndef RAYS_HOST_EMUL
+    if (P.zf_lds) {  // wave-uniform
+      const eq_lds_ptr f = (eq_lds_ptr)(unsigned long long)P.zf_lds + 4 * (i - 1);
+      f0 = f[0]; f1 = f[1]; f2 = f[2]; f3 = f[3];
+    } else
+#endif
+    {
+      const double* f = P.zf_fspl + 4 * (long long)(i - 1);
+      f0 = f[0]; f1 = f[1]; f2 = f[2]; f3 = f[3];
+    }
+    re = f0 + dx * (f1 + dx * (f2 + dx * f3));
   } else {  // asymptotic expansion :408-414 (unreachable from damp_fund_ECH: |xi| <= 5)
     const double A[6] = {1., 1. / 2., 3. / 4., 15. / 8., 105. / 16., 945. / 32.};
     const double z_inv = 1.0 / z;

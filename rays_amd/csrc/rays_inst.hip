@@ -42,7 +42,7 @@ hipError_t launch_one(const DevParams& P, const TraceArgs& A, hipStream_t stream
     constexpr size_t lds = 0;
 #else
     // rays_trace.hpp: the point window (0 unless nv = 7 | 8) + the eqdsk 1-D tables where there is room
-    constexpr size_t lds = PointWindow<NV>::kLdsBytes + eq_tab_lds_bytes<EQ, NV>();
+    constexpr size_t lds = PointWindow<NV>::kLdsBytes + eq_tab_lds_bytes<EQ, NV>() + zf_tab_lds_bytes<EQ, NS, NV>();
 #endif
     return launch_persistent(rk4_trace_kernel<EQ, NS, DERIV, NV>, lds, P, A, stream, grid_blocks);
   }

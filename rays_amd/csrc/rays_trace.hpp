@@ -200,5 +200,13 @@ constexpr size_t eq_tab_lds_bytes() {
   return ((EQ & 3) == RAYS_EQ_AXISYM && PointWindow<NV>::kLdsBytes + kEqTabPad + kEqTabBytes <= 160 * 1024)
              ? kEqTabPad + kEqTabBytes : 0;
 }
+// ... and for the Z-function spline table of the damping (DevParams::zf_lds; 2001 x 4 doubles = 64 KB in RAYS):
+// kernels with the absorbed-power row whose window leaves room for it
+constexpr size_t kZfTabBytes = 65536 + 64;
+template <int EQ, int NS, int NV>
+constexpr size_t zf_tab_lds_bytes() {
+  return (RayVec<(EQ & kEqMultiSpec) != 0, NS, NV>::DAMP &&
+          PointWindow<NV>::kLdsBytes + eq_tab_lds_bytes<EQ, NV>() + kZfTabBytes <= 160 * 1024) ? kZfTabBytes : 0;
+}
 
 }  // namespace rays
