@@ -160,3 +160,17 @@ def test_ray_launcher_and_deposition_config_errors_need_no_gpu():
     q.nv, q.damping_model = 7, 0
     with pytest.raises(hip.RaysHipError, match="damping"):
         hip.deposition_device(q, "Ptotal_psi", 100, 1, 1, 1, 1, 1, None, 1)
+
+
+def test_bench_gpus_n_is_never_a_silent_one_gpu_run():
+    """`bench.py --gpus N` (VERDICT r01 / ADVICE): without a launcher it starts its own N ranks and refuses when
+    fewer than N devices are visible; under a launcher that started another number of ranks it refuses too."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RAYS_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "must start exactly --gpus ranks" in (r.stderr + r.stdout)
