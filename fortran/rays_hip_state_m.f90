@@ -37,6 +37,9 @@ module rays_hip_state_m
          & a_alphan1 => alphan1, a_alphan2 => alphan2, d_scrape_off, T_scrape_off, &
          & a_alphat1 => alphat1, a_alphat2 => alphat2
     use eqdsk_magnetics_spline_interp_m, only : Psi_profile, T_profile
+    use solovev_magnetics_m, only : m_rmaj => rmaj, m_kappa => kappa, m_bphi0 => bphi0, m_iota0 => iota0, &
+         & m_outer_boundary => outer_boundary, m_psiB => psiB, m_rmin => box_rmin, m_rmax => box_rmax, &
+         & m_zmin => box_zmin, m_zmax => box_zmax
     use eqdsk_utilities_m, only : PSIBOUND
     use density_spline_interp_m, only : ne_profile_N
     use temperature_spline_interp_m, only : Te_profileN, Ti_profileN
@@ -115,7 +118,8 @@ module rays_hip_state_m
        p%solovev%box_zmin = box_zmin ; p%solovev%box_zmax = box_zmax
     case ('axisym_toroid')
        p%equilib_model = RAYS_EQ_AXISYM
-       p%axisym%magnetics_model = pick(magnetics_model, [character(len=32) :: 'eqdsk_magnetics_spline_interp'])
+       p%axisym%magnetics_model = pick(magnetics_model, [character(len=32) :: 'eqdsk_magnetics_spline_interp', &
+            & 'solovev_magnetics'])
        p%axisym%density_prof_model = pick(a_dens, [character(len=32) :: 'constant', 'parabolic', 'density_spline_interp'])
        p%axisym%t_prof_model = 0 ; p%axisym%alphat1 = 0. ; p%axisym%alphat2 = 0.
        do is = 0, nspec
@@ -127,14 +131,29 @@ module rays_hip_state_m
        p%axisym%box_zmin = a_zmin ; p%axisym%box_zmax = a_zmax
        p%axisym%plasma_psi_limit = plasma_psi_limit
        p%axisym%psiB = PSIBOUND     ! already PSIBOUND - PSIAXIS (eqdsk_magnetics_spline_interp_m.f90:172)
+       if (trim(magnetics_model) == 'solovev_magnetics') then
+          ! /solovev_magnetics_list/ travels in p%solovev (solovev_magnetics_m.f90:24-35); its own inner box
+          ! (the 'R/z out_of_bounds' errors, :147-148) may differ from the one axisym_toroid_eq checks
+          p%solovev%rmaj = m_rmaj ; p%solovev%kappa = m_kappa ; p%solovev%bphi0 = m_bphi0
+          p%solovev%iota0 = m_iota0 ; p%solovev%outer_bound = m_outer_boundary ; p%solovev%psiB = m_psiB
+          p%solovev%box_rmin = m_rmin ; p%solovev%box_rmax = m_rmax
+          p%solovev%box_zmin = m_zmin ; p%solovev%box_zmax = m_zmax
+          p%axisym%psiB = m_psiB
+       end if
        p%axisym%alphan1 = a_alphan1 ; p%axisym%alphan2 = a_alphan2
        p%axisym%d_scrape_off = d_scrape_off ; p%axisym%T_scrape_off = T_scrape_off
        ! spline tables built by initialize_eqdsk_magnetics_spline_interp / initialize_*_spline_interp
-       t_rg = Psi_profile%x_grid ; t_zg = Psi_profile%y_grid ; t_psi = Psi_profile%fspl
-       t_rbg = T_profile%x_grid ; t_rb = T_profile%fspl
-       tab%nr = Psi_profile%nx ; tab%nz = Psi_profile%ny ; tab%n_rb = T_profile%nx
-       tab%r_grid = c_loc(t_rg) ; tab%z_grid = c_loc(t_zg) ; tab%psi_fspl = c_loc(t_psi)
-       tab%rb_grid = c_loc(t_rbg) ; tab%rb_fspl = c_loc(t_rb)
+       ! (an analytic magnetics model has no psi / R*Bphi tables: nr = nz = n_rb = 0, profile tables only)
+       tab%nr = 0 ; tab%nz = 0 ; tab%n_rb = 0
+       tab%r_grid = c_null_ptr ; tab%z_grid = c_null_ptr ; tab%psi_fspl = c_null_ptr
+       tab%rb_grid = c_null_ptr ; tab%rb_fspl = c_null_ptr
+       if (allocated(Psi_profile%fspl)) then
+          t_rg = Psi_profile%x_grid ; t_zg = Psi_profile%y_grid ; t_psi = Psi_profile%fspl
+          t_rbg = T_profile%x_grid ; t_rb = T_profile%fspl
+          tab%nr = Psi_profile%nx ; tab%nz = Psi_profile%ny ; tab%n_rb = T_profile%nx
+          tab%r_grid = c_loc(t_rg) ; tab%z_grid = c_loc(t_zg) ; tab%psi_fspl = c_loc(t_psi)
+          tab%rb_grid = c_loc(t_rbg) ; tab%rb_fspl = c_loc(t_rb)
+       end if
        tab%n_ne = 0 ; tab%n_te = 0 ; tab%n_ti = 0
        tab%ne_grid = c_null_ptr ; tab%ne_fspl = c_null_ptr
        tab%te_grid = c_null_ptr ; tab%te_fspl = c_null_ptr
@@ -151,9 +170,11 @@ module rays_hip_state_m
           t_tig = Ti_profileN%x_grid ; t_ti = Ti_profileN%fspl
           tab%n_ti = Ti_profileN%nx ; tab%ti_grid = c_loc(t_tig) ; tab%ti_fspl = c_loc(t_ti)
        end if
-       if (rays_hip_set_axisym_tables(tab) /= 0) then
-          call last_error_string(msg)
-          write(0,*) trim(who)//': ', trim(msg) ; stop 1
+       if (tab%nr > 0 .or. tab%n_ne > 0 .or. tab%n_te > 0 .or. tab%n_ti > 0) then   ! (analytic everything: no tables)
+          if (rays_hip_set_axisym_tables(tab) /= 0) then
+             call last_error_string(msg)
+             write(0,*) trim(who)//': ', trim(msg) ; stop 1
+          end if
        end if
     case default
        write(0,*) trim(who)//': equilib_model not on the device path = ', trim(equilib_model); stop 1

@@ -59,7 +59,11 @@ enum { RAYS_SOLOVEV_N_CONSTANT = 0, RAYS_SOLOVEV_N_PARABOLIC };
 enum { RAYS_SOLOVEV_T_ZERO = 0, RAYS_SOLOVEV_T_PARABOLIC = 2 };
 
 /* axisym_toroid_eq_m.f90:56-100: magnetics / profile model strings */
-enum { RAYS_AXI_MAG_EQDSK_SPLINE = 0 }; /* 'eqdsk_magnetics_spline_interp' (the only one on the device) */
+enum { RAYS_AXI_MAG_EQDSK_SPLINE = 0, /* 'eqdsk_magnetics_spline_interp' */
+       RAYS_AXI_MAG_SOLOVEV = 1 };    /* 'solovev_magnetics' (solovev_magnetics_m.f90): the analytic Solovev field under
+                                         the axisym_toroid profile models; its /solovev_magnetics_list/ travels in
+                                         rays_params_t.solovev (rmaj, kappa, bphi0, iota0, outer_bound = outer_boundary,
+                                         psiB, box_*), and axisym.box_* / psiB repeat the box and psiB */
 enum { RAYS_AXI_N_CONSTANT = 0, RAYS_AXI_N_PARABOLIC, RAYS_AXI_N_SPLINE };
 enum { RAYS_AXI_T_ZERO = 0, RAYS_AXI_T_CONSTANT, RAYS_AXI_T_PARABOLIC, RAYS_AXI_T_SPLINE };
 
@@ -78,6 +82,8 @@ enum {
   RAYS_STOP_AXI_R_OUT_OF_BOX = 22, /* 'R_out_of_box'            axisym_toroid_eq_m.f90:263 */
   RAYS_STOP_AXI_Z_OUT_OF_BOX = 23, /* 'Z_out_of_box'            axisym_toroid_eq_m.f90:267 */
   RAYS_STOP_OUT_OF_PLASMA = 24,    /* 'out_of_plasma'           axisym_toroid_eq_m.f90:288 */
+  RAYS_STOP_SOLMAG_R_OUT_OF_BOUNDS = 25, /* 'R out_of_bounds'   solovev_magnetics_m.f90:147 */
+  RAYS_STOP_SOLMAG_Z_OUT_OF_BOUNDS = 26, /* 'z out_of_bounds'   solovev_magnetics_m.f90:148 */
   RAYS_STOP_INFINITE_VG_RHS = 30,  /* 'infinite Vg'             eqn_ray.f90:142 */
   RAYS_STOP_RAY_STALLED = 31,      /* 'ray stalled'             eqn_ray.f90:168 */
   RAYS_STOP_DISP_RESIDUAL = 40,    /* 'dispersion_residual'     check_save.f90:70 */
@@ -191,6 +197,8 @@ int rays_hip_set_zfun_table(const double* fspl_re, int nx, double x_min, double 
  *   psi_fspl(4,4,nr,nz) Fortran order, on r_grid(nr) x z_grid(nz);   Psi - PSIAXIS
  *   rb_fspl(4,n_rb) on rb_grid:   T = R*Bphi
  *   ne/te/ti_fspl(4,n) on *_grid (psiN 0..1): profiles normalised to 1 on axis; n = 0 if unused.
+ * magnetics_model = 'solovev_magnetics' (analytic field) has no psi / R*Bphi tables: the call is needed only
+ * when n or T are splined, with nr = nz = n_rb = 0 and the profile tables alone.
  * The library copies everything; set before tracing. */
 typedef struct rays_axisym_tables {
   int32_t nr, nz, n_rb, n_ne, n_te, n_ti;

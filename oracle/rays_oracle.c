@@ -401,31 +401,28 @@ static void spl2_fpp(double x, double y, double out[6]) {
  *   axisym_toroid_eq_m.f90:215-362, eqdsk_magnetics_spline_interp_m.f90:206-282,
  *   density_spline_interp_m.f90:109-130, temperature_spline_interp_m.f90
  * ------------------------------------------------------------------------------------------ */
-static int axisym_eq(const rays_params_t* P, const double rvec[3], double bvec[3], double gbt[3][3],
-                     double* ns, double (*gradns)[3], double* ts, double (*gradts)[3], int check_box) {
-  const rays_axisym_params_t* S = &P->axisym;
-  const int nspec = P->nspec;
-  const double Tiny = 10.0e-14;
+/* solovev_magnetics        solovev_magnetics_m.f90:127-181 (+ solovev_magnetics_psi :183-213): the magnetics of
+ * solovev_eq above, statement for statement, as a magnetics model of axisym_toroid_eq.  Returns its own box flag
+ * ('R out_of_bounds' / 'z out_of_bounds': the same box as the caller's, without the caller's 1e-13 margin). */
+static int solovev_magnetics(const rays_params_t* P, const double rvec[3], double bvec[3], double gbt[3][3],
+                             double* psiN_out, double gpN[3]) {
+  const rays_solovev_params_t* S = &P->solovev;
   int err = 0;
-  const double x = rvec[0], y = rvec[1], z = rvec[2];
-  const double r = sqrt(x * x + y * y);
-  if (r < S->box_rmin - Tiny || r > S->box_rmax + Tiny) err = RAYS_STOP_AXI_R_OUT_OF_BOX;
-  if (z < S->box_zmin - Tiny || z > S->box_zmax + Tiny) err = RAYS_STOP_AXI_Z_OUT_OF_BOX;
-  if (err && check_box) return err;
-  err = 0;
-  double f6[6], RBphi, RBphiR;
-  spl2_fpp(r, z, f6);
-  const double psi = f6[0], PsiR = f6[1], PsiZ = f6[2], PsiRR = f6[3], PsiRZ = f6[4], PsiZZ = f6[5];
-  spl1_fp(AX.rb_grid, AX.rb_fspl, AX.n_rb, r, &RBphi, &RBphiR);
-  const double br = PsiZ / r, bz = -PsiR / r, bphi = RBphi / r;
-  const double gradpsi[3] = {-x * bz, -y * bz, r * br};
-  const double psiN = psi / S->psiB;
-  const double gpN[3] = {gradpsi[0] / S->psiB, gradpsi[1] / S->psiB, gradpsi[2] / S->psiB};
-  const double dbrdr = -br / r + PsiRZ / r;
-  const double dbrdz = PsiZZ / r;
-  const double dbzdr = -bz / r - PsiRR / r;
-  const double dbzdz = -PsiRZ / r;
-  const double dbphidr = (RBphiR - bphi) / r;
+  double x = rvec[0], y = rvec[1], z = rvec[2];
+  double r = sqrt(x * x + y * y);
+  if (r < S->box_rmin || r > S->box_rmax) err = RAYS_STOP_SOLMAG_R_OUT_OF_BOUNDS; /* :147 */
+  if (z < S->box_zmin || z > S->box_zmax) err = RAYS_STOP_SOLMAG_Z_OUT_OF_BOUNDS; /* :148 */
+  double bp0 = S->bphi0 * S->iota0;
+  double psi, gradpsi[3];
+  solovev_psi(P, rvec, &psi, gradpsi, psiN_out, gpN); /* solovev_magnetics_psi == solovev_psi, term for term */
+  double br = -bp0 * r * z / sq(S->rmaj * S->kappa);
+  double bz = bp0 * (sq(z / (S->rmaj * S->kappa)) + .5 * (sq(r / S->rmaj) - 1.));
+  double bphi = S->bphi0 * S->rmaj / r;
+  double dbrdr = br / r;
+  double dbrdz = -bp0 * r / sq(S->rmaj * S->kappa);
+  double dbzdr = bp0 * r / sq(S->rmaj);
+  double dbzdz = bp0 * 2. * z / sq(S->rmaj * S->kappa);
+  double dbphidr = -bphi / r;
   bvec[0] = br * x / r - bphi * y / r;
   bvec[1] = br * y / r + bphi * x / r;
   bvec[2] = bz;
@@ -438,6 +435,58 @@ static int axisym_eq(const rays_params_t* P, const double rvec[3], double bvec[3
   gbt[0][2] = dbzdr * x / r;
   gbt[1][2] = dbzdr * y / r;
   gbt[2][2] = dbzdz;
+  return err;
+}
+
+static int axisym_eq(const rays_params_t* P, const double rvec[3], double bvec[3], double gbt[3][3],
+                     double* ns, double (*gradns)[3], double* ts, double (*gradts)[3], int check_box) {
+  const rays_axisym_params_t* S = &P->axisym;
+  const int nspec = P->nspec;
+  const double Tiny = 10.0e-14;
+  int err = 0;
+  const double x = rvec[0], y = rvec[1], z = rvec[2];
+  const double r = sqrt(x * x + y * y);
+  if (r < S->box_rmin - Tiny || r > S->box_rmax + Tiny) err = RAYS_STOP_AXI_R_OUT_OF_BOX;
+  if (z < S->box_zmin - Tiny || z > S->box_zmax + Tiny) err = RAYS_STOP_AXI_Z_OUT_OF_BOX;
+  if (err && check_box) return err;
+  err = 0;
+  double psiN_m, gpN_m[3];
+  int mag_err = 0;
+  if (S->magnetics_model == RAYS_AXI_MAG_SOLOVEV) {
+    mag_err = solovev_magnetics(P, rvec, bvec, gbt, &psiN_m, gpN_m);
+    if (mag_err && check_box) return mag_err; /* (the reference goes on with an undefined psiN: within 1e-13 of the box) */
+  }
+  double psiN = 0., gpN[3] = {0., 0., 0.};
+  if (S->magnetics_model == RAYS_AXI_MAG_SOLOVEV) {
+    psiN = psiN_m;
+    gpN[0] = gpN_m[0]; gpN[1] = gpN_m[1]; gpN[2] = gpN_m[2];
+  } else { /* eqdsk_magnetics_spline_interp */
+    double f6[6], RBphi, RBphiR;
+    spl2_fpp(r, z, f6);
+    const double psi = f6[0], PsiR = f6[1], PsiZ = f6[2], PsiRR = f6[3], PsiRZ = f6[4], PsiZZ = f6[5];
+    spl1_fp(AX.rb_grid, AX.rb_fspl, AX.n_rb, r, &RBphi, &RBphiR);
+    const double br = PsiZ / r, bz = -PsiR / r, bphi = RBphi / r;
+    const double gradpsi[3] = {-x * bz, -y * bz, r * br};
+    psiN = psi / S->psiB;
+    gpN[0] = gradpsi[0] / S->psiB; gpN[1] = gradpsi[1] / S->psiB; gpN[2] = gradpsi[2] / S->psiB;
+    const double dbrdr = -br / r + PsiRZ / r;
+    const double dbrdz = PsiZZ / r;
+    const double dbzdr = -bz / r - PsiRR / r;
+    const double dbzdz = -PsiRZ / r;
+    const double dbphidr = (RBphiR - bphi) / r;
+    bvec[0] = br * x / r - bphi * y / r;
+    bvec[1] = br * y / r + bphi * x / r;
+    bvec[2] = bz;
+    gbt[0][0] = (dbrdr * sq(x) + br * sq(y) / r + (-dbphidr + bphi / r) * x * y) / sq(r);
+    gbt[1][0] = ((dbrdr - br / r) * x * y - dbphidr * sq(y) - bphi * sq(x) / r) / sq(r);
+    gbt[2][0] = dbrdz * x / r;
+    gbt[0][1] = ((dbrdr - br / r) * x * y + dbphidr * sq(x) + bphi * sq(y) / r) / sq(r);
+    gbt[1][1] = (dbrdr * sq(y) + br * sq(x) / r + (dbphidr - bphi / r) * x * y) / sq(r);
+    gbt[2][1] = dbrdz * y / r;
+    gbt[0][2] = dbzdr * x / r;
+    gbt[1][2] = dbzdr * y / r;
+    gbt[2][2] = dbzdz;
+  }
   if (psiN > S->plasma_psi_limit) err = RAYS_STOP_OUT_OF_PLASMA; /* :288 */
 
   /* density :290-312 */
@@ -1140,7 +1189,9 @@ int rays_oracle_check_params(const rays_params_t* P) {
                    (P->integrate_eq_gradients ? 5 : 0))
     return 3;
   if (P->damping_model == RAYS_DAMP_FUND_ECH && !zf_fspl) return 6;
-  if (P->equilib_model == RAYS_EQ_AXISYM && (!AX.psi_fspl || !AX.rb_fspl)) return 7;
+  if (P->equilib_model == RAYS_EQ_AXISYM && P->axisym.magnetics_model == RAYS_AXI_MAG_EQDSK_SPLINE &&
+      (!AX.psi_fspl || !AX.rb_fspl))
+    return 7;
   if (P->nv > RAYS_ORACLE_NV_MAX) return 3;
   if (P->equilib_model == RAYS_EQ_SOLOVEV)
     for (int is = 0; is <= P->nspec; is++)

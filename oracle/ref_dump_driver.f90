@@ -18,6 +18,8 @@
 ! When linked as oracle/_ref/rays_hip_dropin the same driver runs with trace_rays replaced by
 ! fortran/trace_rays_hip.f90 (the C-ABI drop-in), so both binaries write the same format.
 program ref_dump_driver
+    use damping_m, only : damping_model
+    use solovev_magnetics_m, only : m_psiB => psiB
     use constants_m, only : rkind, clight, eps0
     use species_m, only : nspec, qs, ms, n0s, t0s, eta
     use rf_m, only : omgrf, k0, dispersion_resid_limit
@@ -46,7 +48,7 @@ program ref_dump_driver
 
     logical :: read_input = .true.
     character(len=256) :: fname, sval
-    integer :: u, u2, stat, probe_stride, reps, irep, iray, j, nprobe, is, n_ne, n_te, n_ti, ip
+    integer :: u, u2, stat, probe_stride, reps, irep, iray, j, nprobe, is, n_ne, n_te, n_ti, ip, np_dump
     real(kind=rkind) :: t0, t1, wall, resid, s
     real(kind=rkind), allocatable :: v(:), dvds(:)
     real(kind=rkind) :: dddx(3), dddk(3), dddw, ndx(3), ndk(3), ndw, nvec(3)
@@ -152,13 +154,17 @@ program ref_dump_driver
     end if
 
     call get_environment_variable('RAYS_DUMP_DEPOSITION', sval, status=stat)
-    if (stat == 0 .and. len_trim(sval) > 0 .and. nv >= 8 .and. &
+    if (stat == 0 .and. len_trim(sval) > 0 .and. nv >= 8 .and. trim(damping_model) /= 'no_damp' .and. &
       & (trim(equilib_model) == 'axisym_toroid' .or. trim(equilib_model) == 'slab')) then
        call initialize_deposition_profiles(.false.)     ! default n_bins (no post_process_rays.in)
+       ! axisym_toroid with an analytic magnetics model has no rho(psiN) spline and the reference's
+       ! axisym_toroid_rho does not implement it (axisym_toroid_eq_m.f90:398-430): 'Ptotal_psi' (profile 1) only
+       np_dump = n_profiles
+       if (trim(equilib_model) == 'axisym_toroid' .and. .not. allocated(rho_profile%fspl)) np_dump = 1
        open(newunit=u2, file=trim(sval), access='stream', form='unformatted', status='replace')
-       write(u2) n_profiles, profiles_1D(1)%n_bins, nray
+       write(u2) np_dump, profiles_1D(1)%n_bins, nray
        write(u2) initial_ray_power(1:nray)
-       if (trim(equilib_model) == 'axisym_toroid') then   ! rho(psiN) spline of the eqdsk equilibrium
+       if (trim(equilib_model) == 'axisym_toroid' .and. allocated(rho_profile%fspl)) then   ! rho(psiN) spline of the eqdsk equilibrium
           write(u2) rho_profile%nx
           write(u2) rho_profile%x_grid, rho_profile%fspl
        else
@@ -166,30 +172,37 @@ program ref_dump_driver
        end if
 #ifdef RAYS_DROPIN
        ! drop-in binary: the profiles come from the GPU (fortran/deposition_profiles_hip.f90), same record layout
-       if (trim(equilib_model) == 'axisym_toroid') then
+       if (trim(equilib_model) == 'axisym_toroid' .and. allocated(rho_profile%fspl)) then
           if (rays_hip_set_rho_table(rho_profile%x_grid, rho_profile%fspl, int(rho_profile%nx, c_int)) /= 0) stop 1
        end if
        allocate(hwork(profiles_1D(1)%n_bins, nray), hprofile(profiles_1D(1)%n_bins, n_profiles), hq(n_profiles))
-       do ip = 1, n_profiles
+       do ip = 1, np_dump
           call deposition_profile_hip(trim(profiles_1D(ip)%profile_name), profiles_1D(ip)%n_bins, hwork, &
                & hprofile(:, ip), hq(ip))
           write(u2) profiles_1D(ip)%profile_name, profiles_1D(ip)%grid_min, profiles_1D(ip)%grid_max
           write(u2) hwork
        end do
-       do ip = 1, n_profiles
+       do ip = 1, np_dump
           write(u2) hprofile(:, ip), hq(ip)
        end do
        close(u2)
 #else
-       do ip = 1, n_profiles          ! per-ray binned arrays, as calculate_deposition_profiles fills them
+       do ip = 1, np_dump             ! per-ray binned arrays, as calculate_deposition_profiles fills them
           do iray = 1, nray
              call bin_a_ray(profiles_1D(ip), iray)
           end do
           write(u2) profiles_1D(ip)%profile_name, profiles_1D(ip)%grid_min, profiles_1D(ip)%grid_max
           write(u2) profiles_1D(ip)%work
        end do
-       call calculate_deposition_profiles                ! the reference's own sums
-       do ip = 1, n_profiles
+       if (np_dump == n_profiles) then
+          call calculate_deposition_profiles             ! the reference's own sums
+       else                                              ! its two statements for the profiles that exist (:250-251)
+          do ip = 1, np_dump
+             profiles_1D(ip)%profile(:) = sum(profiles_1D(ip)%work, 2)
+             profiles_1D(ip)%Q_sum = sum(profiles_1D(ip)%profile)
+          end do
+       end if
+       do ip = 1, np_dump
           write(u2) profiles_1D(ip)%profile, profiles_1D(ip)%Q_sum
        end do
        close(u2)
@@ -198,16 +211,22 @@ program ref_dump_driver
 
     call get_environment_variable('RAYS_DUMP_AXISYM', sval, status=stat)
     if (stat == 0 .and. len_trim(sval) > 0 .and. trim(equilib_model) == 'axisym_toroid') then
-       ! spline tables of the eqdsk equilibrium (host objects of quick_cube_splines_m)
+       ! spline tables of the eqdsk equilibrium (host objects of quick_cube_splines_m); an analytic magnetics
+       ! model has only the profile tables (nr = nz = n_rb = 0)
        open(newunit=u2, file=trim(sval), access='stream', form='unformatted', status='replace')
        n_ne = 0 ; n_te = 0 ; n_ti = 0
        if (allocated(ne_profile_N%fspl)) n_ne = ne_profile_N%nx
        if (allocated(Te_profileN%fspl)) n_te = Te_profileN%nx
        if (allocated(Ti_profileN%fspl)) n_ti = Ti_profileN%nx
-       write(u2) Psi_profile%nx, Psi_profile%ny, T_profile%nx, n_ne, n_te, n_ti
-       write(u2) ax_rmin, ax_rmax, ax_zmin, ax_zmax, plasma_psi_limit, PSIBOUND
-       write(u2) Psi_profile%x_grid, Psi_profile%y_grid, Psi_profile%fspl
-       write(u2) T_profile%x_grid, T_profile%fspl
+       if (allocated(Psi_profile%fspl)) then
+          write(u2) Psi_profile%nx, Psi_profile%ny, T_profile%nx, n_ne, n_te, n_ti
+          write(u2) ax_rmin, ax_rmax, ax_zmin, ax_zmax, plasma_psi_limit, PSIBOUND
+          write(u2) Psi_profile%x_grid, Psi_profile%y_grid, Psi_profile%fspl
+          write(u2) T_profile%x_grid, T_profile%fspl
+       else
+          write(u2) 0, 0, 0, n_ne, n_te, n_ti
+          write(u2) ax_rmin, ax_rmax, ax_zmin, ax_zmax, plasma_psi_limit, m_psiB   ! psiB of solovev_magnetics_m
+       end if
        if (n_ne > 0) write(u2) ne_profile_N%x_grid, ne_profile_N%fspl
        if (n_te > 0) write(u2) Te_profileN%x_grid, Te_profileN%fspl
        if (n_ti > 0) write(u2) Ti_profileN%x_grid, Ti_profileN%fspl

@@ -94,6 +94,8 @@ const FlagText kFlags[] = {
     {RAYS_STOP_AXI_R_OUT_OF_BOX, "R_out_of_box"},
     {RAYS_STOP_AXI_Z_OUT_OF_BOX, "Z_out_of_box"},
     {RAYS_STOP_OUT_OF_PLASMA, "out_of_plasma"},
+    {RAYS_STOP_SOLMAG_R_OUT_OF_BOUNDS, "R out_of_bounds"},
+    {RAYS_STOP_SOLMAG_Z_OUT_OF_BOUNDS, "z out_of_bounds"},
     {RAYS_STOP_INFINITE_VG_RHS, "infinite Vg"},
     {RAYS_STOP_RAY_STALLED, "ray stalled"},
     {RAYS_STOP_DISP_RESIDUAL, "dispersion_residual"},
@@ -188,7 +190,16 @@ int get_axisym_device(rays::DevParams* D) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_mu);
-  if (g_axi.nr <= 1 || g_axi.nz <= 1 || g_axi.n_rb <= 1)
+  const bool analytic = D->a_mag_model == RAYS_AXI_MAG_SOLOVEV;  // 'solovev_magnetics': no psi / RBphi tables
+  if (analytic && g_axi.blob.empty()) {
+    D->a_nr = D->a_nz = D->a_n_rb = D->a_n_ne = D->a_n_te = D->a_n_ti = 0;
+    D->a_r_grid = D->a_z_grid = D->a_psi_fspl = D->a_rb_grid = D->a_rb_fspl = nullptr;
+    D->a_ne_grid = D->a_ne_fspl = D->a_te_grid = D->a_te_fspl = D->a_ti_grid = D->a_ti_fspl = nullptr;
+    D->a_tab1d_doubles = 0;
+    D->a_lds_tab = D->a_lds_rz = 0;
+    return 0;
+  }
+  if (!analytic && (g_axi.nr <= 1 || g_axi.nz <= 1 || g_axi.n_rb <= 1))
     return fail("equilib_model = 'axisym_toroid' needs rays_hip_set_axisym_tables() first");
   if ((int)g_axi_dev.size() <= dev) g_axi_dev.resize(dev + 1);
   ZfunDevice& z = g_axi_dev[dev];
@@ -313,8 +324,10 @@ int rays_hip_set_zfun_table(const double* fspl_re, int nx, double x_min, double 
 }
 
 int rays_hip_set_axisym_tables(const rays_axisym_tables_t* t) {
-  if (!t || t->nr < 2 || t->nz < 2 || t->n_rb < 2 || !t->r_grid || !t->z_grid || !t->psi_fspl || !t->rb_grid ||
-      !t->rb_fspl)
+  // (magnetics_model = 'solovev_magnetics' with splined profiles: nr = nz = n_rb = 0, profile tables only)
+  const bool profiles_only = t && t->nr == 0 && t->nz == 0 && t->n_rb == 0 && (t->n_ne > 0 || t->n_te > 0 || t->n_ti > 0);
+  if (!t || (!profiles_only && (t->nr < 2 || t->nz < 2 || t->n_rb < 2 || !t->r_grid || !t->z_grid || !t->psi_fspl ||
+                                !t->rb_grid || !t->rb_fspl)))
     return fail("rays_hip_set_axisym_tables: bad tables");
   if ((t->n_ne > 0 && (!t->ne_grid || !t->ne_fspl)) || (t->n_te > 0 && (!t->te_grid || !t->te_fspl)) ||
       (t->n_ti > 0 && (!t->ti_grid || !t->ti_fspl)))
@@ -442,8 +455,12 @@ int rays_hip_check_params(const rays_params_t* p) {
         return fail("SOLOVEV: t_prof_model must be 'zero' or 'parabolic' ('constant' leaves ts undefined in the reference)");
   } else if (p->equilib_model == RAYS_EQ_AXISYM) {
     const rays_axisym_params_t& a = p->axisym;
-    if (a.magnetics_model != RAYS_AXI_MAG_EQDSK_SPLINE)
-      return fail("axisym_toroid: only magnetics_model = 'eqdsk_magnetics_spline_interp' is on the device path");
+    if (a.magnetics_model != RAYS_AXI_MAG_EQDSK_SPLINE && a.magnetics_model != RAYS_AXI_MAG_SOLOVEV)
+      return fail("axisym_toroid: magnetics_model must be 'eqdsk_magnetics_spline_interp' or 'solovev_magnetics' on "
+                  "the device path ('eqdsk_magnetics_lin_interp' is not)");
+    if (a.magnetics_model == RAYS_AXI_MAG_SOLOVEV &&
+        (p->solovev.outer_bound < p->solovev.rmaj || p->solovev.outer_bound >= std::sqrt(2.) * p->solovev.rmaj))
+      return fail("Inner boundary complex, outer_bound >=  sqrt2*rmaj");  // solovev_magnetics_m.f90:99-103
     if (a.density_prof_model < 0 || a.density_prof_model > RAYS_AXI_N_SPLINE)
       return fail("axisym_toroid_eq: Unknown density_prof_model");
     for (int is = 0; is <= p->nspec; is++)
@@ -1069,6 +1086,8 @@ int rays_hip_deposition_device(const rays_params_t* p, int which, int n_bins, in
     return fail("initialize_deposition_profiles: unimplemented equilib_model");
   if (p->nv < 8 || p->damping_model == RAYS_DAMP_NONE)
     return fail("rays_hip_deposition: needs a run with damping (ray_vec(8) = absorbed power fraction)");
+  if (p->equilib_model == RAYS_EQ_AXISYM && p->axisym.magnetics_model == RAYS_AXI_MAG_SOLOVEV && which == RAYS_DEP_PTOTAL_RHO)
+    return fail("axisym_toroid_rho: rho is only implemented for eqdsk_magnetics_spline_interp");  // axisym_toroid_eq_m.f90:398-430
   if (p->equilib_model == RAYS_EQ_SLAB ? which != RAYS_DEP_PTOTAL_X
                                        : (which != RAYS_DEP_PTOTAL_PSI && which != RAYS_DEP_PTOTAL_RHO))
     return fail("initialize_deposition_profiles: unimplemented profile for this equilib_model");  // :162-169, 204-212

@@ -38,8 +38,14 @@ RAYS_DEV double dep_grid_value(const DevParams& P, const DepArgs& D, const doubl
   if (D.which == 2) return x;  // Ptotal_x_slab_evaluator (deposition_profiles_m.f90:449)
   const double r = sqrt(x * x + y * y);
   double f6[6];
-  spl2_fpp(P, r, z, f6);
-  const double psiN = f6[0] / P.a_psiB;  // psiN = Psi/PSIBOUND (:314)
+  double psiN;
+  if (P.a_mag_model == RAYS_AXI_MAG_SOLOVEV) {  // axisym_toroid_psi -> solovev_magnetics_psi (solovev_magnetics_m.f90:199-207)
+    const double psi = P.half_bp0 * (sq(r * z / P.rk) + sq(r * r - P.rmaj2) / P.rmaj2 / 4.);
+    psiN = psi / P.psiB;
+  } else {
+    spl2_fpp(P, r, z, f6);
+    psiN = f6[0] / P.a_psiB;  // psiN = Psi/PSIBOUND (:314)
+  }
   if (D.which == 0) return psiN;
   double rho, drho;
   spl1_fp(D.rho_grid, D.rho_fspl, D.n_rho, psiN, rho, drho);

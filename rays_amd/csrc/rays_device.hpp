@@ -42,6 +42,7 @@ struct DevParams {
                                             // at the very end of the RHS' dependency chain, nothing hides its latency
   // axisym_toroid + eqdsk spline magnetics (axisym_toroid_eq_m.f90, eqdsk_magnetics_spline_interp_m.f90)
   int a_n_model, a_nr, a_nz, a_n_rb, a_n_ne, a_n_te, a_n_ti;
+  int a_mag_model;                          // RAYS_AXI_MAG_*: eqdsk bicubic spline | analytic Solovev field
   int a_t_model[RAYS_NS0];
   double a_box_rmin, a_box_rmax, a_box_zmin, a_box_zmax, a_psi_limit, a_psiB, a_inv_psiB;
   double a_an1, a_an2, a_d_scrape, a_T_scrape;
@@ -359,17 +360,10 @@ RAYS_DEV int slab_fields(const DevParams& P, const double rvec[3], double bvec[3
   return err;
 }
 
-// solovev_eq + solovev_psi  solovev_eq_m.f90:122-276, 280-322
-template <int NS, bool UE>
-RAYS_DEV int solovev_fields(const DevParams& P, const double rvec[3], double bvec[3],
-                            double gbt[3][3], double ns[NS], double gradns[NS][3], double ts[NS],
-                            double gradts[NS][3], bool check_box) {
-  int err = 0;
-  const double x = rvec[0], y = rvec[1], z = rvec[2];
-  const double r = sqrt(x * x + y * y);
-  if (r < P.box_rmin || r > P.box_rmax) err = RAYS_STOP_R_OUT_OF_BOX;  // :155
-  if (z < P.box_zmin || z > P.box_zmax) err = RAYS_STOP_Z_OUT_OF_BOX;  // :156
-  if (!check_box) err = 0;
+// Magnetics of the Solovev equilibrium: B, grad B tensor, psiN, grad psiN at (x, y, z), r = sqrt(x^2 + y^2).
+//   solovev_eq_m.f90:159-204 + solovev_psi :308-318  ==  solovev_magnetics_m.f90:154-181 + :199-207, term for term
+RAYS_DEV void solovev_magnetics(const DevParams& P, double x, double y, double z, double r, double bvec[3],
+                                double gbt[3][3], double& psiN, double gradpsiN[3]) {
   const double bp0 = P.bp0;
   const Recip Rr = make_recip(r), Rr2 = make_recip(sq(r));
   const Recip Rrk = const_recip(P.rk, P.inv_rk), Rrk2 = const_recip(P.rk2, P.inv_rk2);
@@ -381,8 +375,10 @@ RAYS_DEV int solovev_fields(const DevParams& P, const double rvec[3], double bve
   // solovev_psi :308-318
   const double psi = P.half_bp0 * (sq(div(r * z, Rrk)) + div(sq(r * r - P.rmaj2), Rrmaj2) * 0.25);
   const double gradpsi[3] = {x * bz, y * bz, -r * br};
-  const double psiN = div(psi, RpsiB);
-  const double gradpsiN[3] = {div(gradpsi[0], RpsiB), div(gradpsi[1], RpsiB), div(gradpsi[2], RpsiB)};
+  psiN = div(psi, RpsiB);
+  gradpsiN[0] = div(gradpsi[0], RpsiB);
+  gradpsiN[1] = div(gradpsi[1], RpsiB);
+  gradpsiN[2] = div(gradpsi[2], RpsiB);
 
   const double bphi = div(P.bphi0_rmaj, Rr);
   const double br_r = div(br, Rr), bphi_r = div(bphi, Rr);  // br/r, bphi/r (each appears 3x)
@@ -404,6 +400,21 @@ RAYS_DEV int solovev_fields(const DevParams& P, const double rvec[3], double bve
   gbt[0][2] = div(dbzdr * x, Rr);
   gbt[1][2] = div(dbzdr * y, Rr);
   gbt[2][2] = dbzdz;
+}
+
+// solovev_eq + solovev_psi  solovev_eq_m.f90:122-276, 280-322
+template <int NS, bool UE>
+RAYS_DEV int solovev_fields(const DevParams& P, const double rvec[3], double bvec[3],
+                            double gbt[3][3], double ns[NS], double gradns[NS][3], double ts[NS],
+                            double gradts[NS][3], bool check_box) {
+  int err = 0;
+  const double x = rvec[0], y = rvec[1], z = rvec[2];
+  const double r = sqrt(x * x + y * y);
+  if (r < P.box_rmin || r > P.box_rmax) err = RAYS_STOP_R_OUT_OF_BOX;  // :155
+  if (z < P.box_zmin || z > P.box_zmax) err = RAYS_STOP_Z_OUT_OF_BOX;  // :156
+  if (!check_box) err = 0;
+  double psiN, gradpsiN[3];
+  solovev_magnetics(P, x, y, z, r, bvec, gbt, psiN, gradpsiN);
 
 #pragma unroll
   for (int is = 0; is < NS; is++) {
@@ -571,36 +582,53 @@ RAYS_DEV int axisym_fields(const DevParams& P, const double rvec[3], double bvec
   const double r = sqrt(x * x + y * y);
   if (r < P.a_box_rmin - Tiny || r > P.a_box_rmax + Tiny) err = RAYS_STOP_AXI_R_OUT_OF_BOX;  // :261-264
   if (z < P.a_box_zmin - Tiny || z > P.a_box_zmax + Tiny) err = RAYS_STOP_AXI_Z_OUT_OF_BOX;  // :265-268
-  const bool boxed = check_box && err != 0;  // reference returns here; fields below are then unused
-  double f6[6], RBphi, RBphiR;
-  spl2_fpp(P, r, z, f6);
-  const double psi = f6[0], PsiR = f6[1], PsiZ = f6[2], PsiRR = f6[3], PsiRZ = f6[4], PsiZZ = f6[5];
-  spl1_tab(P, P.a_rb_grid, P.a_rb_fspl, P.a_n_rb, r, RBphi, RBphiR);
-  const Recip Rr = make_recip(r), Rr2 = make_recip(sq(r));
-  const Recip RpsiB = const_recip(P.a_psiB, P.a_inv_psiB);
-  const double br = div(PsiZ, Rr), bz = div(-PsiR, Rr), bphi = div(RBphi, Rr);
-  const double gradpsi[3] = {-x * bz, -y * bz, r * br};
-  const double psiN = div(psi, RpsiB);
-  const double gpN[3] = {div(gradpsi[0], RpsiB), div(gradpsi[1], RpsiB), div(gradpsi[2], RpsiB)};
-  const double br_r = div(br, Rr), bphi_r = div(bphi, Rr);
-  const double dbrdr = -br_r + div(PsiRZ, Rr);
-  const double dbrdz = div(PsiZZ, Rr);
-  const double dbzdr = div(-bz, Rr) - div(PsiRR, Rr);
-  const double dbzdz = div(-PsiRZ, Rr);
-  const double dbphidr = div(RBphiR - bphi, Rr);
-  bvec[0] = div(br * x, Rr) - div(bphi * y, Rr);
-  bvec[1] = div(br * y, Rr) + div(bphi * x, Rr);
-  bvec[2] = bz;
-  const double x2 = sq(x), y2 = sq(y);
-  gbt[0][0] = div(dbrdr * x2 + div(br * y2, Rr) + (-dbphidr + bphi_r) * x * y, Rr2);
-  gbt[1][0] = div((dbrdr - br_r) * x * y - dbphidr * y2 - div(bphi * x2, Rr), Rr2);
-  gbt[2][0] = div(dbrdz * x, Rr);
-  gbt[0][1] = div((dbrdr - br_r) * x * y + dbphidr * x2 + div(bphi * y2, Rr), Rr2);
-  gbt[1][1] = div(dbrdr * y2 + div(br * x2, Rr) + (dbphidr - bphi_r) * x * y, Rr2);
-  gbt[2][1] = div(dbrdz * y, Rr);
-  gbt[0][2] = div(dbzdr * x, Rr);
-  gbt[1][2] = div(dbzdr * y, Rr);
-  gbt[2][2] = dbzdz;
+  bool boxed = check_box && err != 0;  // reference returns here; fields below are then unused
+  double psiN, gpN[3];
+  if (P.a_mag_model == RAYS_AXI_MAG_SOLOVEV) {  // wave-uniform
+    // solovev_magnetics (solovev_magnetics_m.f90:127-181): its own test of the same box, without the 1e-13
+    // margin of the test above ('R out_of_bounds' / 'z out_of_bounds'; the reference then goes on with an
+    // undefined psiN -- here the ray stops with that flag)
+    int merr = 0;
+    if (r < P.box_rmin || r > P.box_rmax) merr = RAYS_STOP_SOLMAG_R_OUT_OF_BOUNDS;
+    if (z < P.box_zmin || z > P.box_zmax) merr = RAYS_STOP_SOLMAG_Z_OUT_OF_BOUNDS;
+    if (check_box && !boxed && merr != 0) {
+      boxed = true;
+      err = merr;
+    }
+    solovev_magnetics(P, x, y, z, r, bvec, gbt, psiN, gpN);
+  } else {
+    double f6[6], RBphi, RBphiR;
+    spl2_fpp(P, r, z, f6);
+    const double psi = f6[0], PsiR = f6[1], PsiZ = f6[2], PsiRR = f6[3], PsiRZ = f6[4], PsiZZ = f6[5];
+    spl1_tab(P, P.a_rb_grid, P.a_rb_fspl, P.a_n_rb, r, RBphi, RBphiR);
+    const Recip Rr = make_recip(r), Rr2 = make_recip(sq(r));
+    const Recip RpsiB = const_recip(P.a_psiB, P.a_inv_psiB);
+    const double br = div(PsiZ, Rr), bz = div(-PsiR, Rr), bphi = div(RBphi, Rr);
+    const double gradpsi[3] = {-x * bz, -y * bz, r * br};
+    psiN = div(psi, RpsiB);
+    gpN[0] = div(gradpsi[0], RpsiB);
+    gpN[1] = div(gradpsi[1], RpsiB);
+    gpN[2] = div(gradpsi[2], RpsiB);
+    const double br_r = div(br, Rr), bphi_r = div(bphi, Rr);
+    const double dbrdr = -br_r + div(PsiRZ, Rr);
+    const double dbrdz = div(PsiZZ, Rr);
+    const double dbzdr = div(-bz, Rr) - div(PsiRR, Rr);
+    const double dbzdz = div(-PsiRZ, Rr);
+    const double dbphidr = div(RBphiR - bphi, Rr);
+    bvec[0] = div(br * x, Rr) - div(bphi * y, Rr);
+    bvec[1] = div(br * y, Rr) + div(bphi * x, Rr);
+    bvec[2] = bz;
+    const double x2 = sq(x), y2 = sq(y);
+    gbt[0][0] = div(dbrdr * x2 + div(br * y2, Rr) + (-dbphidr + bphi_r) * x * y, Rr2);
+    gbt[1][0] = div((dbrdr - br_r) * x * y - dbphidr * y2 - div(bphi * x2, Rr), Rr2);
+    gbt[2][0] = div(dbrdz * x, Rr);
+    gbt[0][1] = div((dbrdr - br_r) * x * y + dbphidr * x2 + div(bphi * y2, Rr), Rr2);
+    gbt[1][1] = div(dbrdr * y2 + div(br * x2, Rr) + (dbphidr - bphi_r) * x * y, Rr2);
+    gbt[2][1] = div(dbrdz * y, Rr);
+    gbt[0][2] = div(dbzdr * x, Rr);
+    gbt[1][2] = div(dbzdr * y, Rr);
+    gbt[2][2] = dbzdz;
+  }
   if (!boxed) err = 0;
   if (!boxed && psiN > P.a_psi_limit) err = RAYS_STOP_OUT_OF_PLASMA;  // :288
 

@@ -103,7 +103,8 @@ template <int EQ>
 RAYS_DEV void launch_gradpsi(const DevParams& P, const double rvec[3], double g[3]) {
   const double x = rvec[0], y = rvec[1], z = rvec[2];
   const double r = sqrt(x * x + y * y);
-  if ((EQ & 3) == RAYS_EQ_SOLOVEV) {
+  if ((EQ & 3) == RAYS_EQ_SOLOVEV || ((EQ & 3) == RAYS_EQ_AXISYM && P.a_mag_model == RAYS_AXI_MAG_SOLOVEV)) {
+    // (axisym_toroid_psi -> solovev_magnetics_psi: the same statements, solovev_magnetics_m.f90:199-207)
     const Recip Rrk = const_recip(P.rk, P.inv_rk), Rrk2 = const_recip(P.rk2, P.inv_rk2);
     const Recip Rrmaj = const_recip(P.rmaj, P.inv_rmaj);
     const double br = div(-P.bp0 * r * z, Rrk2);

@@ -10,6 +10,7 @@ the device is bit-identical to the Fortran host's.
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import Any, Dict
 
 import numpy as np
@@ -21,7 +22,7 @@ ODE = {"RK4_ODE": 0, "SG_ODE": 1}
 DERIV = {"cold": 0, "numerical": 1}
 RAY_PARAM = {"arcl": 0, "time": 1}
 EQUILIB = {"slab": 0, "solovev": 1, "axisym_toroid": 2}
-AXI_MAGNETICS = {"eqdsk_magnetics_spline_interp": 0}
+AXI_MAGNETICS = {"eqdsk_magnetics_spline_interp": 0, "solovev_magnetics": 1}
 AXI_N = {"constant": 0, "parabolic": 1, "density_spline_interp": 2}
 AXI_T = {"zero": 0, "constant": 1, "parabolic": 2, "temperature_spline_interp": 3}
 SLAB_BX = {"zero": 0}
@@ -330,10 +331,25 @@ def params_from_namelist(nml: Dict[str, Dict[str, Any]], axisym_tables: Dict[str
                 getattr(q, name)[i] = float(vals[i])
     elif p.equilib_model == EQUILIB["axisym_toroid"]:
         s = nml.get("axisym_toroid_eq_list", {})
-        if axisym_tables is None:
-            raise ConfigError("equilib_model='axisym_toroid' needs axisym_tables (host-built spline tables)")
         q = p.axisym
         q.magnetics_model = _lookup(AXI_MAGNETICS, s.get("magnetics_model", ""), "magnetics model")
+        if q.magnetics_model == AXI_MAGNETICS["solovev_magnetics"]:
+            # /solovev_magnetics_list/ (solovev_magnetics_m.f90:60-125): travels in p.solovev; the box and psiB
+            # it hands to axisym_toroid_eq are repeated in p.axisym
+            m = nml.get("solovev_magnetics_list", {})
+            v = p.solovev
+            for name in ("rmaj", "kappa", "bphi0", "iota0", "box_rmin", "box_rmax", "box_zmin", "box_zmax"):
+                setattr(v, name, float(m.get(name, 0.0)))
+            v.outer_bound = float(m.get("outer_boundary", 0.0))
+            if v.outer_bound < v.rmaj or v.outer_bound >= math.sqrt(2.0) * v.rmaj:
+                raise ConfigError("Inner boundary complex, outer_bound >=  sqrt2*rmaj")  # :99-103 (`stop`)
+            bp0 = v.bphi0 * v.iota0
+            t = v.outer_bound * v.outer_bound - v.rmaj * v.rmaj
+            v.psiB = 0.5 * bp0 * (t * t) / (v.rmaj * v.rmaj) / 4.0                       # :106
+            axisym_tables = dict(axisym_tables or {}, box_rmin=v.box_rmin, box_rmax=v.box_rmax,
+                                 box_zmin=v.box_zmin, box_zmax=v.box_zmax, psiB=v.psiB)
+        elif axisym_tables is None:
+            raise ConfigError("equilib_model='axisym_toroid' needs axisym_tables (host-built spline tables)")
         q.density_prof_model = _lookup(AXI_N, s.get("density_prof_model", ""), "density_prof_model")
         tm = _arr(s.get("temperature_prof_model"), NS0, " ")
         for i in range(nspec + 1):

@@ -58,6 +58,8 @@ def load_axisym_tables(namelist_path: str, nml: Dict[str, Dict[str, Any]]) -> Op
 
     if str(nml.get("equilibrium_list", {}).get("equilib_model", "")).strip() != "axisym_toroid":
         return None
+    if str(nml.get("axisym_toroid_eq_list", {}).get("magnetics_model", "")).strip() == "solovev_magnetics":
+        return None   # analytic magnetics: nothing to load (spline PROFILE models would still need their tables)
     eq = str(nml.get("eqdsk_magnetics_spline_interp_list", {}).get("eqdsk_file_name", "")).strip()
     f = os.path.join(os.path.dirname(os.path.abspath(namelist_path)), eq + ".tables.npz")
     if not os.path.exists(f):

@@ -17,14 +17,18 @@ GOLDEN_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_n
                 "gold_axisym64_eqdsk_damp_sg", "gold_axisym64_eqdsk_tspline_rk4_num", "gold_axisym16_eqdsk_zexit_rk4",
                 "gold_slab_toroid_parab_arcl_grad_rk4", "gold_slab_shear_gauss_3spec_sg_num", "gold_slab_lin2_rk4_num",
                 "gold_slab_ns1_rk4", "gold_solovev64_damp_grad_rk4", "gold_slab_6spec_sg", "gold_solovev64_4spec_rk4_num",
-                "gold_solovev64_damp_multi_sg", "gold_slab16_damp_multi_grad_rk4"]
+                "gold_solovev64_damp_multi_sg", "gold_slab16_damp_multi_grad_rk4",
+                "gold_axisym64_solmag_damp_rk4", "gold_axisym64_solmag_sg_num",
+                "gold_axisym64_solmag_splines_grad_rk4"]
 
 
 def load_golden(name):
     g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"), allow_pickle=False)
     nml = read_namelist(os.path.join(ROOT, "configs", str(g["config"])))
     tab = {k[4:]: (float(g[k]) if g[k].ndim == 0 else g[k]) for k in g.files if k.startswith("axi_")}
-    if tab:  # eqdsk equilibrium: hand the host-built spline tables to every implementation under test
+    # eqdsk equilibrium (or an analytic magnetics model with splined profiles): hand the host-built spline tables
+    # to every implementation under test
+    if any(np.size(tab.get(k, ())) for k in ("r_grid", "ne_grid", "te_grid", "ti_grid")):
         from rays_amd import hip
         from tests import emul_lib, oracle_lib
 

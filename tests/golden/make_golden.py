@@ -74,6 +74,10 @@ CASES = [
     # multi_spec_damping: one absorbed-power row per species behind the total (nv = 10 | 15; ode_m.f90:169)
     ("gold_solovev64_damp_multi_sg", "gold_solovev64_damp_multi_sg.in", list(range(0, 64, 5)), 0, 0),
     ("gold_slab16_damp_multi_grad_rk4", "gold_slab16_damp_multi_grad_rk4.in", None, 0, 0),
+    # axisym_toroid with the analytic Solovev field as its magnetics model (solovev_magnetics_m.f90)
+    ("gold_axisym64_solmag_damp_rk4", "gold_axisym64_solmag_damp_rk4.in", list(range(0, 64, 5)), 10, 60),
+    ("gold_axisym64_solmag_sg_num", "gold_axisym64_solmag_sg_num.in", list(range(0, 64, 7)), 0, 0),
+    ("gold_axisym64_solmag_splines_grad_rk4", "gold_axisym64_solmag_splines_grad_rk4.in", list(range(0, 64, 9)), 25, 0),
 ]
 
 
@@ -151,7 +155,8 @@ def main():
             host_tabs = {k: np.asarray(v) for k, v in axi.items()}
             if dep is not None and "rho_grid" in dep:   # rho(psiN) spline, for the Ptotal_rho profile
                 host_tabs.update(rho_grid=dep["rho_grid"], rho_fspl=dep["rho_fspl"])
-            np.savez_compressed(os.path.join(ROOT, "configs", "solovev_65x65.geqdsk.tables.npz"), **host_tabs)
+            if len(axi["r_grid"]):                      # (an analytic magnetics model has profile tables only)
+                np.savez_compressed(os.path.join(ROOT, "configs", "solovev_65x65.geqdsk.tables.npz"), **host_tabs)
         if dep is not None:
             # deposition profiles of the FULL fan + the full-fan trajectories they
             # are binned from (v(1:3), v(8)) so the device binner can be checked without a re-trace

@@ -25,10 +25,8 @@ template <int EQ, int DERIV>
 static int run(int solver, int ns, int nv, const rays::DevParams& D, const rays::TraceArgs& A) {
   if (ns == 2 && nv == 7) return run1<EQ, DERIV, 2, 7>(solver, D, A);
   if (ns == 2 && nv == 8) return run1<EQ, DERIV, 2, 8>(solver, D, A);
-  if constexpr ((EQ & 3) != 2) {
-    if (ns == 2 && nv == 12) return run1<EQ, DERIV, 2, 12>(solver, D, A);
-    if (ns == 2 && nv == 13) return run1<EQ, DERIV, 2, 13>(solver, D, A);
-  }
+  if (ns == 2 && nv == 12) return run1<EQ, DERIV, 2, 12>(solver, D, A);
+  if (ns == 2 && nv == 13) return run1<EQ, DERIV, 2, 13>(solver, D, A);
   if constexpr ((EQ & 3) == 0) {
     if (ns == 1 && nv == 7) return run1<EQ, DERIV, 1, 7>(solver, D, A);
     if (ns == 3 && nv == 7) return run1<EQ, DERIV, 3, 7>(solver, D, A);
@@ -106,7 +104,7 @@ extern "C" int rays_emul_trace_ex(const rays_params_t* p, int nray, const double
     D.zf_fspl = g_zfun.data(); D.zf_nx = g_zf_nx; D.zf_xmin = g_zf_xmin; D.zf_xmax = g_zf_xmax;
   }
   if (p->equilib_model == RAYS_EQ_AXISYM) {
-    if (g_axi[2].empty()) return 3;
+    if (p->axisym.magnetics_model == RAYS_AXI_MAG_EQDSK_SPLINE && g_axi[2].empty()) return 3;
     D.a_nr = g_axi_n[0]; D.a_nz = g_axi_n[1]; D.a_n_rb = g_axi_n[2]; D.a_n_ne = g_axi_n[3]; D.a_n_te = g_axi_n[4]; D.a_n_ti = g_axi_n[5];
     D.a_r_grid = g_axi[0].data(); D.a_z_grid = g_axi[1].data(); D.a_psi_fspl = g_axi[2].data();
     D.a_rb_grid = g_axi[3].data(); D.a_rb_fspl = g_axi[4].data(); D.a_ne_grid = g_axi[5].data(); D.a_ne_fspl = g_axi[6].data();
@@ -153,7 +151,7 @@ extern "C" int rays_emul_ray_init(const rays_params_t* p, const rays_fan_t* fan,
   F.launch = launch.data();
   rays::DevParams D = make_dev_params(*p);
   if (p->equilib_model == RAYS_EQ_AXISYM) {
-    if (g_axi[2].empty()) return 3;
+    if (p->axisym.magnetics_model == RAYS_AXI_MAG_EQDSK_SPLINE && g_axi[2].empty()) return 3;
     D.a_nr = g_axi_n[0]; D.a_nz = g_axi_n[1]; D.a_n_rb = g_axi_n[2]; D.a_n_ne = g_axi_n[3]; D.a_n_te = g_axi_n[4]; D.a_n_ti = g_axi_n[5];
     D.a_r_grid = g_axi[0].data(); D.a_z_grid = g_axi[1].data(); D.a_psi_fspl = g_axi[2].data();
     D.a_rb_grid = g_axi[3].data(); D.a_rb_fspl = g_axi[4].data(); D.a_ne_grid = g_axi[5].data(); D.a_ne_fspl = g_axi[6].data();
@@ -181,7 +179,8 @@ extern "C" int rays_emul_deposition(const rays_params_t* p, int which, int n_bin
                                     const double* rho_fspl, int n_rho, double* work, double* profile) {
   rays::DevParams D = make_dev_params(*p);
   if (which != 2) {
-    if (p->equilib_model != RAYS_EQ_AXISYM || g_axi[2].empty()) return 3;
+    if (p->equilib_model != RAYS_EQ_AXISYM) return 3;
+    if (p->axisym.magnetics_model == RAYS_AXI_MAG_EQDSK_SPLINE && g_axi[2].empty()) return 3;
     D.a_nr = g_axi_n[0]; D.a_nz = g_axi_n[1]; D.a_n_rb = g_axi_n[2];
     D.a_r_grid = g_axi[0].data(); D.a_z_grid = g_axi[1].data(); D.a_psi_fspl = g_axi[2].data();
     D.a_rb_grid = g_axi[3].data(); D.a_rb_fspl = g_axi[4].data();

@@ -105,6 +105,24 @@ def test_deposition_source_on_host_equals_reference():
         assert q == g["dep_q_sum"][which]
 
 
+def test_solovev_magnetics_deposition_source_on_host_equals_reference():
+    """'Ptotal_psi' of an axisym_toroid run with magnetics_model = 'solovev_magnetics' (axisym_toroid_psi ->
+    solovev_magnetics_psi, solovev_magnetics_m.f90:199-244): work, profile and Q_sum bit for bit.  ('Ptotal_rho'
+    does not exist for this magnetics model in the reference, axisym_toroid_eq_m.f90:398-430.)"""
+    from tests.common import padded_full_trajectories
+    g, nml, p = load_golden("gold_axisym64_solmag_damp_rk4")
+    assert [str(n) for n in g["dep_names"]] == ["Ptotal_psi"]
+    rv = padded_full_trajectories(g, p)
+    work, prof = emul_lib.deposition(p, 0, int(g["dep_n_bins"]), rv, g["npoints_full"], g["dep_power"],
+                                     np.zeros(1), np.zeros(4))
+    np.testing.assert_array_equal(work, g["dep_work"][0])
+    np.testing.assert_array_equal(prof, g["dep_profile"][0])
+    q = 0.0
+    for x in prof:
+        q = q + x
+    assert q == g["dep_q_sum"][0] and q > 0.1
+
+
 def test_slab_deposition_source_on_host_equals_reference():
     """'Ptotal_x' of a slab run with damping (Ptotal_x_slab_evaluator, deposition_profiles_m.f90:438-452;
     grid = the slab box in x): work, profile and Q_sum bit for bit."""
