@@ -100,9 +100,9 @@ const KernelEntry kEntries[] = {
 #if defined(RAYS_SG_PROFILE) && RAYS_INST_SOLVER == 1
 // developer builds only: per-section wave clocks of this group's SG kernels
 extern "C" int RAYS_CAT(rays_debug_sg_profile, RAYS_INST_SOLVER, RAYS_INST_EQ, RAYS_INST_DERIV, RAYS_INST_UE, RAYS_INST_MS)(unsigned long long* out, int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sg_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sg_prof), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
   if (reset) {
-    unsigned long long z[16] = {0};
+    unsigned long long z[32] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_sg_prof), z, sizeof z) != hipSuccess) return 1;
   }
   return 0;

@@ -27,8 +27,8 @@ namespace rays {
 // Developer build (-DRAYS_SG_PROFILE): wave-clock spent per section of the wave loop, summed over all
 // waves into g_sg_prof (read back by rays_hip_debug_sg_profile).  Not compiled into the product.
 #ifdef RAYS_SG_PROFILE
-__device__ unsigned long long g_sg_prof[16];
-#define SG_PROF_DECL unsigned long long prof_t = clock64(), prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+__device__ unsigned long long g_sg_prof[32];
+#define SG_PROF_DECL unsigned long long prof_t = clock64(), prof_acc[32] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define SG_PROF(slot)                              \
   do {                                             \
     const unsigned long long now_ = clock64();     \
@@ -37,7 +37,7 @@ __device__ unsigned long long g_sg_prof[16];
   } while (0)
 #define SG_PROF_FLUSH                                                          \
   if ((threadIdx.x & 63) == 0)                                                 \
-    for (int i_ = 0; i_ < 16; i_++) atomicAdd(&g_sg_prof[i_], prof_acc[i_]);
+    for (int i_ = 0; i_ < 32; i_++) atomicAdd(&g_sg_prof[i_], prof_acc[i_]);
 #else
 #define SG_PROF_DECL
 #define SG_PROF(slot) ((void)0)
@@ -624,6 +624,7 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
             double rk[NV], rkm1[NV];  // phi(:,k), phi(:,k-1)
             F.get(k, rk);
             F.get(km1, rkm1);
+            SG_PROF(16);
 #pragma unroll
             for (int l = 0; l < NV; l++) {
               const double ph1 = F.lo[0][l];
@@ -638,6 +639,7 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
               const double q = div(f[l] - ph1, wt[l]);
               erk = erk + q * q;
             }
+            SG_PROF(17);
             if (0 < km2) erkm2 = absh * S.sig(km1) * gstr(km2) * sqrt(erkm2);
             if (0 <= km2) erkm1 = absh * S.sig(k) * gstr(km1) * sqrt(erkm1);
             const double err = absh * sqrt(erk) * (S.g(k) - S.g(kp1));
@@ -648,6 +650,7 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
             } else if (0 == km2) {
               if (erkm1 <= 0.5 * erk) knew = km1;
             }
+            SG_PROF(18);
             if (err <= eps) {
               // ---- successful: correct (ode_RAYS.f90:1128-1142) ----
               kold = k;
@@ -667,6 +670,7 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
               }
               pc = PC_F3;
               seg = SEG_WAIT;
+              SG_PROF(19);
             } else {
               // ---- failed step: restore, shrink (ode_RAYS.f90:1086-1120) ----
               fl &= ~FL_PHASE1;
@@ -709,6 +713,7 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
             F.set(kp1, d1);
             F.set(kp2, d2);
             F.add(k, d1);
+            SG_PROF(20);
             double erkp1 = 0.0;
             if (knew == km1 || k == 12) fl &= ~FL_PHASE1;
             if (fl & FL_PHASE1) {
@@ -737,6 +742,7 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
                 erk = erkp1;
               }
             }
+            SG_PROF(21);
             double hnew = h + h;
             if (!(fl & FL_PHASE1)) {
               const double two_k1 = (double)(2 << k);  // two(k+1) = 2**(k+1)
@@ -834,6 +840,7 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
             t = tout;
             pc = PC_CHECK;
             seg = SEG_WAIT;
+            SG_PROF(22);
           } else if (maxnum <= nostep) {  // :536-548
             stop = (fl & FL_STIFF) ? RAYS_STOP_SG_STIFF : RAYS_STOP_SG_MAXNUM;
             sg_save_y<NV>(A_hot, yy);  // y = yy; t = x
@@ -856,6 +863,7 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
                 sm += q * q;
               }
               round_ = twou * sqrt(sm);  // :844
+              SG_PROF(23);
               if (p5eps < round_) {
                 eps = 2.0 * round_ * (1.0 + fouru);
                 seg = SEG_CRASH;
@@ -1010,6 +1018,7 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
 #pragma unroll
             for (int l = 0; l < NV; l++) pp[l] = yy[l] + h * pp[l];
           }
+          SG_PROF(24);
           xold = x;
           x = x + h;
           absh = fabs(h);
