@@ -150,6 +150,13 @@
           type(rays_axisym_tables_t), intent(in) :: t
        end function rays_hip_set_axisym_tables
 
+       ! magnetics_model = 'eqdsk_magnetics_lin_interp': eqdsk_utilities_m's R_grid, Z_grid, Psi, T (rb_fspl), dR, dZ
+       integer(c_int) function rays_hip_set_eqdsk_lin_tables(t, dR, dZ) bind(C, name='rays_hip_set_eqdsk_lin_tables')
+          import :: c_int, c_double, rays_axisym_tables_t
+          type(rays_axisym_tables_t), intent(in) :: t
+          real(c_double), value :: dR, dZ
+       end function rays_hip_set_eqdsk_lin_tables
+
        integer(c_int) function rays_hip_check_params(p) bind(C, name='rays_hip_check_params')
           import :: c_int, rays_params_t
           type(rays_params_t), intent(in) :: p

@@ -12,6 +12,7 @@ module rays_hip_state_m
 
     ! contiguous TARGET copies of the host's spline objects (c_loc needs a target)
     real(c_double), allocatable, target, private :: t_rg(:), t_zg(:), t_psi(:,:,:,:), t_rbg(:), t_rb(:,:)
+    real(c_double), allocatable, target, private :: t_lpsi(:,:), t_lt(:)   ! 'eqdsk_magnetics_lin_interp': Psi, T
     real(c_double), allocatable, target, private :: t_neg(:), t_ne(:,:), t_teg(:), t_te(:,:), t_tig(:), t_ti(:,:)
 
  contains
@@ -40,7 +41,8 @@ module rays_hip_state_m
     use solovev_magnetics_m, only : m_rmaj => rmaj, m_kappa => kappa, m_bphi0 => bphi0, m_iota0 => iota0, &
          & m_outer_boundary => outer_boundary, m_psiB => psiB, m_rmin => box_rmin, m_rmax => box_rmax, &
          & m_zmin => box_zmin, m_zmax => box_zmax
-    use eqdsk_utilities_m, only : PSIBOUND
+    use eqdsk_utilities_m, only : PSIBOUND, NRBOX, NZBOX, eq_R_grid => R_grid, eq_Z_grid => Z_grid, eq_Psi => Psi, &
+         & eq_T => T, eq_dR => dR, eq_dZ => dZ
     use density_spline_interp_m, only : ne_profile_N
     use temperature_spline_interp_m, only : Te_profileN, Ti_profileN
 
@@ -119,7 +121,7 @@ module rays_hip_state_m
     case ('axisym_toroid')
        p%equilib_model = RAYS_EQ_AXISYM
        p%axisym%magnetics_model = pick(magnetics_model, [character(len=32) :: 'eqdsk_magnetics_spline_interp', &
-            & 'solovev_magnetics'])
+            & 'solovev_magnetics', 'eqdsk_magnetics_lin_interp'])
        p%axisym%density_prof_model = pick(a_dens, [character(len=32) :: 'constant', 'parabolic', 'density_spline_interp'])
        p%axisym%t_prof_model = 0 ; p%axisym%alphat1 = 0. ; p%axisym%alphat2 = 0.
        do is = 0, nspec
@@ -147,7 +149,13 @@ module rays_hip_state_m
        tab%nr = 0 ; tab%nz = 0 ; tab%n_rb = 0
        tab%r_grid = c_null_ptr ; tab%z_grid = c_null_ptr ; tab%psi_fspl = c_null_ptr
        tab%rb_grid = c_null_ptr ; tab%rb_fspl = c_null_ptr
-       if (allocated(Psi_profile%fspl)) then
+       if (trim(magnetics_model) == 'eqdsk_magnetics_lin_interp') then
+          ! eqdsk_utilities_m after initialize_eqdsk_magnetics_lin_interp (Psi already Psi - PSIAXIS, :139)
+          t_rg = eq_R_grid ; t_zg = eq_Z_grid ; t_lpsi = eq_Psi ; t_lt = eq_T
+          tab%nr = NRBOX ; tab%nz = NZBOX ; tab%n_rb = NRBOX
+          tab%r_grid = c_loc(t_rg) ; tab%z_grid = c_loc(t_zg) ; tab%psi_fspl = c_loc(t_lpsi)
+          tab%rb_fspl = c_loc(t_lt)
+       else if (allocated(Psi_profile%fspl)) then
           t_rg = Psi_profile%x_grid ; t_zg = Psi_profile%y_grid ; t_psi = Psi_profile%fspl
           t_rbg = T_profile%x_grid ; t_rb = T_profile%fspl
           tab%nr = Psi_profile%nx ; tab%nz = Psi_profile%ny ; tab%n_rb = T_profile%nx
@@ -170,7 +178,12 @@ module rays_hip_state_m
           t_tig = Ti_profileN%x_grid ; t_ti = Ti_profileN%fspl
           tab%n_ti = Ti_profileN%nx ; tab%ti_grid = c_loc(t_tig) ; tab%ti_fspl = c_loc(t_ti)
        end if
-       if (tab%nr > 0 .or. tab%n_ne > 0 .or. tab%n_te > 0 .or. tab%n_ti > 0) then   ! (analytic everything: no tables)
+       if (trim(magnetics_model) == 'eqdsk_magnetics_lin_interp') then
+          if (rays_hip_set_eqdsk_lin_tables(tab, eq_dR, eq_dZ) /= 0) then
+             call last_error_string(msg)
+             write(0,*) trim(who)//': ', trim(msg) ; stop 1
+          end if
+       else if (tab%nr > 0 .or. tab%n_ne > 0 .or. tab%n_te > 0 .or. tab%n_ti > 0) then   ! (analytic everything: no tables)
           if (rays_hip_set_axisym_tables(tab) /= 0) then
              call last_error_string(msg)
              write(0,*) trim(who)//': ', trim(msg) ; stop 1

@@ -64,6 +64,10 @@ enum { RAYS_AXI_MAG_EQDSK_SPLINE = 0, /* 'eqdsk_magnetics_spline_interp' */
                                          the axisym_toroid profile models; its /solovev_magnetics_list/ travels in
                                          rays_params_t.solovev (rmaj, kappa, bphi0, iota0, outer_bound = outer_boundary,
                                          psiB, box_*), and axisym.box_* / psiB repeat the box and psiB */
+enum { RAYS_AXI_MAG_EQDSK_LIN = 2 };  /* 'eqdsk_magnetics_lin_interp' (eqdsk_magnetics_lin_interp_m.f90): bilinear
+                                         interpolation of the raw eqdsk Psi(NRBOX, NZBOX) and linear interpolation of
+                                         T(NRBOX), derivatives by the reference's central differences over +-dR, +-dZ
+                                         (eqdsk_utilities_m.f90:144-306); tables: rays_hip_set_eqdsk_lin_tables */
 enum { RAYS_AXI_N_CONSTANT = 0, RAYS_AXI_N_PARABOLIC, RAYS_AXI_N_SPLINE };
 enum { RAYS_AXI_T_ZERO = 0, RAYS_AXI_T_CONSTANT, RAYS_AXI_T_PARABOLIC, RAYS_AXI_T_SPLINE };
 
@@ -209,6 +213,19 @@ typedef struct rays_axisym_tables {
   const double *ti_grid, *ti_fspl;
 } rays_axisym_tables_t;
 int rays_hip_set_axisym_tables(const rays_axisym_tables_t* t);
+
+/* Tables of magnetics_model = 'eqdsk_magnetics_lin_interp' (instead of rays_hip_set_axisym_tables): the host's
+ * eqdsk_utilities_m arrays after initialize_eqdsk_magnetics_lin_interp (eqdsk_magnetics_lin_interp_m.f90:121-141),
+ * in the same struct with this meaning:
+ *   r_grid(nr) = R_grid, z_grid(nz) = Z_grid;   psi_fspl = Psi(nr, nz) Fortran order, PSIAXIS already subtracted;
+ *   rb_fspl = T(nr) (= R*Bphi on R_grid), n_rb = nr, rb_grid unused (may be NULL);
+ *   ne/te/ti_*: the splined profiles as in rays_hip_set_axisym_tables (n = 0 if unused);
+ *   dR, dZ = eqdsk_utilities_m's dR, dZ (HALF the grid spacing, :137-138) -- the steps of GetPsiR .. GetRBphiR.
+ * axisym.box_* and axisym.psiB (= PSIBOUND - PSIAXIS) travel in rays_params_t as for the spline model.
+ * Where the reference's central differences index one cell beyond R_grid / Z_grid (a point in the outermost cells)
+ * it reads the neighbouring column of Psi through Fortran's storage order; the library does the same and clamps only
+ * what would leave the array altogether (undefined in the reference). */
+int rays_hip_set_eqdsk_lin_tables(const rays_axisym_tables_t* t, double dR, double dZ);
 
 /* Validates a parameter block exactly as the reference's `stop 1` configuration checks would;
  * 0 if the device path supports it. */

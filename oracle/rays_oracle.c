@@ -334,6 +334,8 @@ typedef struct {
   int nr, nz, n_rb, n_ne, n_te, n_ti;
   double *r_grid, *z_grid, *psi_fspl, *rb_grid, *rb_fspl, *ne_grid, *ne_fspl, *te_grid, *te_fspl,
       *ti_grid, *ti_fspl;
+  int lin;       /* tables of 'eqdsk_magnetics_lin_interp': psi_fspl = Psi(nr, nz), rb_fspl = T(nr) */
+  double dR, dZ; /* eqdsk_utilities_m: half the grid spacing */
 } axisym_tables;
 static axisym_tables AX;
 
@@ -344,14 +346,20 @@ static double* dup_d(const double* p, size_t n) {
   return q;
 }
 
-int rays_oracle_set_axisym_tables(const rays_axisym_tables_t* t) {
+static int set_tables(const rays_axisym_tables_t* t, int lin, double dR, double dZ);
+int rays_oracle_set_axisym_tables(const rays_axisym_tables_t* t) { return set_tables(t, 0, 0., 0.); }
+/* same meaning as rays_hip_set_eqdsk_lin_tables */
+int rays_oracle_set_eqdsk_lin_tables(const rays_axisym_tables_t* t, double dR, double dZ) { return set_tables(t, 1, dR, dZ); }
+static int set_tables(const rays_axisym_tables_t* t, int lin, double dR, double dZ) {
   free(AX.r_grid); free(AX.z_grid); free(AX.psi_fspl); free(AX.rb_grid); free(AX.rb_fspl);
   free(AX.ne_grid); free(AX.ne_fspl); free(AX.te_grid); free(AX.te_fspl); free(AX.ti_grid); free(AX.ti_fspl);
   memset(&AX, 0, sizeof AX);
   AX.nr = t->nr; AX.nz = t->nz; AX.n_rb = t->n_rb; AX.n_ne = t->n_ne; AX.n_te = t->n_te; AX.n_ti = t->n_ti;
   AX.r_grid = dup_d(t->r_grid, t->nr); AX.z_grid = dup_d(t->z_grid, t->nz);
-  AX.psi_fspl = dup_d(t->psi_fspl, (size_t)16 * t->nr * t->nz);
-  AX.rb_grid = dup_d(t->rb_grid, t->n_rb); AX.rb_fspl = dup_d(t->rb_fspl, (size_t)4 * t->n_rb);
+  AX.lin = lin; AX.dR = dR; AX.dZ = dZ;
+  AX.psi_fspl = dup_d(t->psi_fspl, (size_t)(lin ? 1 : 16) * t->nr * t->nz);
+  AX.rb_grid = lin ? NULL : dup_d(t->rb_grid, t->n_rb);
+  AX.rb_fspl = dup_d(t->rb_fspl, (size_t)(lin ? 1 : 4) * t->n_rb);
   AX.ne_grid = dup_d(t->ne_grid, t->n_ne); AX.ne_fspl = dup_d(t->ne_fspl, (size_t)4 * t->n_ne);
   AX.te_grid = dup_d(t->te_grid, t->n_te); AX.te_fspl = dup_d(t->te_fspl, (size_t)4 * t->n_te);
   AX.ti_grid = dup_d(t->ti_grid, t->n_ti); AX.ti_fspl = dup_d(t->ti_fspl, (size_t)4 * t->n_ti);
@@ -438,6 +446,78 @@ static int solovev_magnetics(const rays_params_t* P, const double rvec[3], doubl
   return err;
 }
 
+/* ---- 'eqdsk_magnetics_lin_interp': eqdsk_utilities_m.f90:144-306, eqdsk_magnetics_lin_interp_m.f90:146-249 ----
+ * GetPsi does not bound its cell indices; where the central differences reach one cell beyond the grid it reads the
+ * neighbouring column of Psi(NRBOX, NZBOX) through the storage order.  Same here; an index outside the array
+ * altogether (undefined in the reference) is clamped. */
+static double lin_psi_at(int i, int j) {
+  long long k = (long long)(i - 1) + (long long)(j - 1) * AX.nr;
+  const long long n = (long long)AX.nr * AX.nz;
+  if (k < 0) k = 0;
+  if (k >= n) k = n - 1;
+  return AX.psi_fspl[k];
+}
+static double lin_getpsi(double R, double Z) { /* :144-162 */
+  const double hr = AX.r_grid[1] - AX.r_grid[0], hz = AX.z_grid[1] - AX.z_grid[0];
+  const int i = 1 + (int)((R - AX.r_grid[0]) / hr);
+  const int j = 1 + (int)((Z - AX.z_grid[0]) / hz);
+  const int ic = i < 1 ? 1 : (i > AX.nr ? AX.nr : i), jc = j < 1 ? 1 : (j > AX.nz ? AX.nz : j);
+  const double x = (R - AX.r_grid[ic - 1]) / hr;
+  const double y = (Z - AX.z_grid[jc - 1]) / hz;
+  return lin_psi_at(i, j) * (1. - x) * (1. - y) + lin_psi_at(i + 1, j) * x * (1. - y) +
+         lin_psi_at(i, j + 1) * (1. - x) * y + lin_psi_at(i + 1, j + 1) * x * y;
+}
+static double lin_getrbphi(double R) { /* :168-184 */
+  const double hr = AX.r_grid[1] - AX.r_grid[0];
+  const int i = 1 + (int)((R - AX.r_grid[0]) / hr);
+  const int ic = i < 1 ? 1 : (i > AX.nr - 1 ? AX.nr - 1 : i);
+  const double x = (R - AX.r_grid[ic - 1]) / hr;
+  return AX.rb_fspl[ic - 1] * (1. - x) + AX.rb_fspl[ic] * x;
+}
+static double lin_psiR(double R, double Z) { return (lin_getpsi(R + AX.dR, Z) - lin_getpsi(R - AX.dR, Z)) / 2. / AX.dR; }
+static double lin_psiZ(double R, double Z) { return (lin_getpsi(R, Z + AX.dZ) - lin_getpsi(R, Z - AX.dZ)) / 2. / AX.dZ; }
+static double lin_psiRR(double R, double Z) {
+  return (lin_getpsi(R + 2. * AX.dR, Z) - 2. * lin_getpsi(R, Z) + lin_getpsi(R - 2. * AX.dR, Z)) / AX.dR / AX.dR;
+}
+static double lin_psiZZ(double R, double Z) {
+  return (lin_getpsi(R, Z + 2. * AX.dZ) - 2. * lin_getpsi(R, Z) + lin_getpsi(R, Z - 2. * AX.dZ)) / AX.dZ / AX.dZ;
+}
+static double lin_psiRZ(double R, double Z) {
+  const double R1 = R - AX.dR, R2 = R + AX.dR, Z1 = Z - AX.dZ, Z2 = Z + AX.dZ;
+  return (lin_getpsi(R2, Z2) - lin_getpsi(R1, Z2) - lin_getpsi(R2, Z1) + lin_getpsi(R1, Z1)) / 4. / AX.dR / AX.dZ;
+}
+static double lin_rbphiR(double R) { return (lin_getrbphi(R + AX.dR) - lin_getrbphi(R - AX.dR)) / 2. / AX.dR; }
+/* eqdsk_magnetics_lin_interp (:146-214) */
+static void lin_magnetics(const rays_params_t* P, const double rvec[3], double bvec[3], double gbt[3][3],
+                          double* psiN, double gpN[3]) {
+  const double x = rvec[0], y = rvec[1], z = rvec[2];
+  const double r = sqrt(x * x + y * y);
+  const double psi = lin_getpsi(r, z);
+  const double br = -lin_psiZ(r, z) / r;
+  const double bz = lin_psiR(r, z) / r;
+  const double bphi = lin_getrbphi(r) / r;
+  const double gradpsi[3] = {x * bz, y * bz, -r * br};
+  *psiN = psi / P->axisym.psiB;
+  gpN[0] = gradpsi[0] / P->axisym.psiB; gpN[1] = gradpsi[1] / P->axisym.psiB; gpN[2] = gradpsi[2] / P->axisym.psiB;
+  const double dbrdr = -br / r - lin_psiRZ(r, z) / r;
+  const double dbrdz = -lin_psiZZ(r, z) / r;
+  const double dbzdr = -bz / r + lin_psiRR(r, z) / r;
+  const double dbzdz = lin_psiRZ(r, z) / r;
+  const double dbphidr = (lin_rbphiR(r) - bphi) / r;
+  bvec[0] = br * x / r - bphi * y / r;
+  bvec[1] = br * y / r + bphi * x / r;
+  bvec[2] = bz;
+  gbt[0][0] = (dbrdr * sq(x) + br * sq(y) / r + (-dbphidr + bphi / r) * x * y) / sq(r);
+  gbt[1][0] = ((dbrdr - br / r) * x * y - dbphidr * sq(y) - bphi * sq(x) / r) / sq(r);
+  gbt[2][0] = dbrdz * x / r;
+  gbt[0][1] = ((dbrdr - br / r) * x * y + dbphidr * sq(x) + bphi * sq(y) / r) / sq(r);
+  gbt[1][1] = (dbrdr * sq(y) + br * sq(x) / r + (dbphidr - bphi / r) * x * y) / sq(r);
+  gbt[2][1] = dbrdz * y / r;
+  gbt[0][2] = dbzdr * x / r;
+  gbt[1][2] = dbzdr * y / r;
+  gbt[2][2] = dbzdz;
+}
+
 static int axisym_eq(const rays_params_t* P, const double rvec[3], double bvec[3], double gbt[3][3],
                      double* ns, double (*gradns)[3], double* ts, double (*gradts)[3], int check_box) {
   const rays_axisym_params_t* S = &P->axisym;
@@ -460,6 +540,8 @@ static int axisym_eq(const rays_params_t* P, const double rvec[3], double bvec[3
   if (S->magnetics_model == RAYS_AXI_MAG_SOLOVEV) {
     psiN = psiN_m;
     gpN[0] = gpN_m[0]; gpN[1] = gpN_m[1]; gpN[2] = gpN_m[2];
+  } else if (S->magnetics_model == RAYS_AXI_MAG_EQDSK_LIN) {
+    lin_magnetics(P, rvec, bvec, gbt, &psiN, gpN);
   } else { /* eqdsk_magnetics_spline_interp */
     double f6[6], RBphi, RBphiR;
     spl2_fpp(r, z, f6);
@@ -1190,7 +1272,10 @@ int rays_oracle_check_params(const rays_params_t* P) {
     return 3;
   if (P->damping_model == RAYS_DAMP_FUND_ECH && !zf_fspl) return 6;
   if (P->equilib_model == RAYS_EQ_AXISYM && P->axisym.magnetics_model == RAYS_AXI_MAG_EQDSK_SPLINE &&
-      (!AX.psi_fspl || !AX.rb_fspl))
+      (!AX.psi_fspl || !AX.rb_fspl || AX.lin))
+    return 7;
+  if (P->equilib_model == RAYS_EQ_AXISYM && P->axisym.magnetics_model == RAYS_AXI_MAG_EQDSK_LIN &&
+      (!AX.psi_fspl || !AX.rb_fspl || !AX.lin))
     return 7;
   if (P->nv > RAYS_ORACLE_NV_MAX) return 3;
   if (P->equilib_model == RAYS_EQ_SOLOVEV)

@@ -18,6 +18,8 @@ int rays_oracle_check_params(const rays_params_t* P);
 int rays_oracle_set_zfun_table(const double* fspl_re, int nx, double x_min, double x_max);
 /* axisym_toroid spline tables (same meaning as rays_hip_set_axisym_tables). */
 int rays_oracle_set_axisym_tables(const rays_axisym_tables_t* t);
+/* tables of magnetics_model = 'eqdsk_magnetics_lin_interp' (same meaning as rays_hip_set_eqdsk_lin_tables) */
+int rays_oracle_set_eqdsk_lin_tables(const rays_axisym_tables_t* t, double dR, double dZ);
 
 /* Same argument meaning as rays_hip_trace (include/rays_hip.h); host pointers; nthreads <= 0 =
  * all OpenMP threads.  nrhs_total (optional) counts eqn_ray calls made by the SG stepper. */

@@ -33,9 +33,10 @@ program ref_dump_driver
     use solovev_eq_m, only : rmaj, kappa, bphi0, iota0, outer_bound, psiB
     use zfunctions_m, only : fsplRe, zf_nx => nx, x_grid_min, x_grid_max
     use axisym_toroid_eq_m, only : ax_rmin => box_rmin, ax_rmax => box_rmax, ax_zmin => box_zmin, &
-         & ax_zmax => box_zmax, plasma_psi_limit
+         & ax_zmax => box_zmax, plasma_psi_limit, magnetics_model
     use eqdsk_magnetics_spline_interp_m, only : Psi_profile, T_profile, rho_profile
-    use eqdsk_utilities_m, only : PSIBOUND
+    use eqdsk_utilities_m, only : PSIBOUND, NRBOX, NZBOX, eq_dR => dR, eq_dZ => dZ, eq_R_grid => R_grid, &
+         & eq_Z_grid => Z_grid, eq_Psi => Psi, eq_T => T
     use density_spline_interp_m, only : ne_profile_N
     use temperature_spline_interp_m, only : Te_profileN, Ti_profileN
     use omp_lib
@@ -218,7 +219,14 @@ program ref_dump_driver
        if (allocated(ne_profile_N%fspl)) n_ne = ne_profile_N%nx
        if (allocated(Te_profileN%fspl)) n_te = Te_profileN%nx
        if (allocated(Ti_profileN%fspl)) n_ti = Ti_profileN%nx
-       if (allocated(Psi_profile%fspl)) then
+       if (trim(magnetics_model) == 'eqdsk_magnetics_lin_interp') then
+          ! eqdsk_utilities_m after initialize_eqdsk_magnetics_lin_interp (n_rb = -1 marks this layout)
+          write(u2) NRBOX, NZBOX, -1, n_ne, n_te, n_ti
+          write(u2) ax_rmin, ax_rmax, ax_zmin, ax_zmax, plasma_psi_limit, PSIBOUND
+          write(u2) eq_dR, eq_dZ
+          write(u2) eq_R_grid, eq_Z_grid, eq_Psi
+          write(u2) eq_T
+       else if (allocated(Psi_profile%fspl)) then
           write(u2) Psi_profile%nx, Psi_profile%ny, T_profile%nx, n_ne, n_te, n_ti
           write(u2) ax_rmin, ax_rmax, ax_zmin, ax_zmax, plasma_psi_limit, PSIBOUND
           write(u2) Psi_profile%x_grid, Psi_profile%y_grid, Psi_profile%fspl

@@ -181,6 +181,8 @@ struct AxisymHost {
   std::vector<double> blob;  // all arrays back to back
   size_t off[11] = {0};      // r_grid z_grid psi rb_grid rb_fspl ne_grid ne_fspl te_grid te_fspl ti_grid ti_fspl
   int nr = 0, nz = 0, n_rb = 0, n_ne = 0, n_te = 0, n_ti = 0;
+  bool lin = false;          // tables of 'eqdsk_magnetics_lin_interp': psi = Psi(nr, nz) raw, rb_fspl = T(nr), rb_grid empty
+  double dR = 0., dZ = 0.;
   unsigned long long version = 0;
 };
 AxisymHost g_axi;
@@ -199,7 +201,10 @@ int get_axisym_device(rays::DevParams* D) {
     D->a_lds_tab = D->a_lds_rz = 0;
     return 0;
   }
-  if (!analytic && (g_axi.nr <= 1 || g_axi.nz <= 1 || g_axi.n_rb <= 1))
+  const bool lin = D->a_mag_model == RAYS_AXI_MAG_EQDSK_LIN;
+  if (lin && !g_axi.lin)
+    return fail("magnetics_model = 'eqdsk_magnetics_lin_interp' needs rays_hip_set_eqdsk_lin_tables() first");
+  if (!analytic && !lin && (g_axi.lin || g_axi.nr <= 1 || g_axi.nz <= 1 || g_axi.n_rb <= 1))
     return fail("equilib_model = 'axisym_toroid' needs rays_hip_set_axisym_tables() first");
   if ((int)g_axi_dev.size() <= dev) g_axi_dev.resize(dev + 1);
   ZfunDevice& z = g_axi_dev[dev];
@@ -219,6 +224,8 @@ int get_axisym_device(rays::DevParams* D) {
   D->a_te_grid = b + g_axi.off[7]; D->a_te_fspl = b + g_axi.off[8];
   D->a_ti_grid = b + g_axi.off[9]; D->a_ti_fspl = b + g_axi.off[10];
   D->a_tab1d_doubles = (int)(g_axi.blob.size() - g_axi.off[3]);  // rb .. ti: contiguous at the end of the blob
+  D->a_lin_dR = g_axi.dR;
+  D->a_lin_dZ = g_axi.dZ;
   D->a_lds_tab = 0;
   D->a_lds_rz = 0;
   return 0;
@@ -323,11 +330,22 @@ int rays_hip_set_zfun_table(const double* fspl_re, int nx, double x_min, double 
   return 0;
 }
 
-int rays_hip_set_axisym_tables(const rays_axisym_tables_t* t) {
+namespace {
+int set_axisym_tables_impl(const rays_axisym_tables_t* t, bool lin, double dR, double dZ);
+}
+int rays_hip_set_axisym_tables(const rays_axisym_tables_t* t) { return set_axisym_tables_impl(t, false, 0., 0.); }
+int rays_hip_set_eqdsk_lin_tables(const rays_axisym_tables_t* t, double dR, double dZ) {
+  if (!t || t->nr < 2 || t->nz < 2 || t->n_rb != t->nr || !t->r_grid || !t->z_grid || !t->psi_fspl || !t->rb_fspl ||
+      !(dR > 0.) || !(dZ > 0.))
+    return fail("rays_hip_set_eqdsk_lin_tables: bad tables");
+  return set_axisym_tables_impl(t, true, dR, dZ);
+}
+namespace {
+int set_axisym_tables_impl(const rays_axisym_tables_t* t, bool lin, double dR, double dZ) {
   // (magnetics_model = 'solovev_magnetics' with splined profiles: nr = nz = n_rb = 0, profile tables only)
   const bool profiles_only = t && t->nr == 0 && t->nz == 0 && t->n_rb == 0 && (t->n_ne > 0 || t->n_te > 0 || t->n_ti > 0);
-  if (!t || (!profiles_only && (t->nr < 2 || t->nz < 2 || t->n_rb < 2 || !t->r_grid || !t->z_grid || !t->psi_fspl ||
-                                !t->rb_grid || !t->rb_fspl)))
+  if (!t || (!profiles_only && !lin && (t->nr < 2 || t->nz < 2 || t->n_rb < 2 || !t->r_grid || !t->z_grid || !t->psi_fspl ||
+                                        !t->rb_grid || !t->rb_fspl)))
     return fail("rays_hip_set_axisym_tables: bad tables");
   if ((t->n_ne > 0 && (!t->ne_grid || !t->ne_fspl)) || (t->n_te > 0 && (!t->te_grid || !t->te_fspl)) ||
       (t->n_ti > 0 && (!t->ti_grid || !t->ti_fspl)))
@@ -337,8 +355,9 @@ int rays_hip_set_axisym_tables(const rays_axisym_tables_t* t) {
   h.blob.clear();
   const double* src[11] = {t->r_grid, t->z_grid, t->psi_fspl, t->rb_grid, t->rb_fspl, t->ne_grid, t->ne_fspl,
                            t->te_grid, t->te_fspl, t->ti_grid, t->ti_fspl};
-  const size_t len[11] = {(size_t)t->nr, (size_t)t->nz, (size_t)16 * t->nr * t->nz, (size_t)t->n_rb,
-                          (size_t)4 * t->n_rb, (size_t)(t->n_ne > 0 ? t->n_ne : 0), (size_t)4 * (t->n_ne > 0 ? t->n_ne : 0),
+  // ('eqdsk_magnetics_lin_interp': raw Psi(nr, nz) and T(nr) in the psi / rb_fspl slots, no rb_grid)
+  const size_t len[11] = {(size_t)t->nr, (size_t)t->nz, (size_t)(lin ? 1 : 16) * t->nr * t->nz, lin ? (size_t)0 : (size_t)t->n_rb,
+                          (size_t)(lin ? 1 : 4) * t->n_rb, (size_t)(t->n_ne > 0 ? t->n_ne : 0), (size_t)4 * (t->n_ne > 0 ? t->n_ne : 0),
                           (size_t)(t->n_te > 0 ? t->n_te : 0), (size_t)4 * (t->n_te > 0 ? t->n_te : 0),
                           (size_t)(t->n_ti > 0 ? t->n_ti : 0), (size_t)4 * (t->n_ti > 0 ? t->n_ti : 0)};
   for (int k = 0; k < 11; k++) {
@@ -348,9 +367,11 @@ int rays_hip_set_axisym_tables(const rays_axisym_tables_t* t) {
   }
   h.nr = t->nr; h.nz = t->nz; h.n_rb = t->n_rb;
   h.n_ne = t->n_ne > 0 ? t->n_ne : 0; h.n_te = t->n_te > 0 ? t->n_te : 0; h.n_ti = t->n_ti > 0 ? t->n_ti : 0;
+  h.lin = lin; h.dR = dR; h.dZ = dZ;
   h.version++;
   return 0;
 }
+}  // namespace
 
 int rays_hip_sizeof_params(void) { return (int)sizeof(rays_params_t); }
 
@@ -455,9 +476,10 @@ int rays_hip_check_params(const rays_params_t* p) {
         return fail("SOLOVEV: t_prof_model must be 'zero' or 'parabolic' ('constant' leaves ts undefined in the reference)");
   } else if (p->equilib_model == RAYS_EQ_AXISYM) {
     const rays_axisym_params_t& a = p->axisym;
-    if (a.magnetics_model != RAYS_AXI_MAG_EQDSK_SPLINE && a.magnetics_model != RAYS_AXI_MAG_SOLOVEV)
-      return fail("axisym_toroid: magnetics_model must be 'eqdsk_magnetics_spline_interp' or 'solovev_magnetics' on "
-                  "the device path ('eqdsk_magnetics_lin_interp' is not)");
+    if (a.magnetics_model != RAYS_AXI_MAG_EQDSK_SPLINE && a.magnetics_model != RAYS_AXI_MAG_SOLOVEV &&
+        a.magnetics_model != RAYS_AXI_MAG_EQDSK_LIN)
+      return fail("axisym_toroid: magnetics_model must be 'eqdsk_magnetics_spline_interp', 'eqdsk_magnetics_lin_interp' "
+                  "or 'solovev_magnetics'");
     if (a.magnetics_model == RAYS_AXI_MAG_SOLOVEV &&
         (p->solovev.outer_bound < p->solovev.rmaj || p->solovev.outer_bound >= std::sqrt(2.) * p->solovev.rmaj))
       return fail("Inner boundary complex, outer_bound >=  sqrt2*rmaj");  // solovev_magnetics_m.f90:99-103
@@ -1086,7 +1108,7 @@ int rays_hip_deposition_device(const rays_params_t* p, int which, int n_bins, in
     return fail("initialize_deposition_profiles: unimplemented equilib_model");
   if (p->nv < 8 || p->damping_model == RAYS_DAMP_NONE)
     return fail("rays_hip_deposition: needs a run with damping (ray_vec(8) = absorbed power fraction)");
-  if (p->equilib_model == RAYS_EQ_AXISYM && p->axisym.magnetics_model == RAYS_AXI_MAG_SOLOVEV && which == RAYS_DEP_PTOTAL_RHO)
+  if (p->equilib_model == RAYS_EQ_AXISYM && p->axisym.magnetics_model != RAYS_AXI_MAG_EQDSK_SPLINE && which == RAYS_DEP_PTOTAL_RHO)
     return fail("axisym_toroid_rho: rho is only implemented for eqdsk_magnetics_spline_interp");  // axisym_toroid_eq_m.f90:398-430
   if (p->equilib_model == RAYS_EQ_SLAB ? which != RAYS_DEP_PTOTAL_X
                                        : (which != RAYS_DEP_PTOTAL_PSI && which != RAYS_DEP_PTOTAL_RHO))

@@ -42,6 +42,8 @@ RAYS_DEV double dep_grid_value(const DevParams& P, const DepArgs& D, const doubl
   if (P.a_mag_model == RAYS_AXI_MAG_SOLOVEV) {  // axisym_toroid_psi -> solovev_magnetics_psi (solovev_magnetics_m.f90:199-207)
     const double psi = P.half_bp0 * (sq(r * z / P.rk) + sq(r * r - P.rmaj2) / P.rmaj2 / 4.);
     psiN = psi / P.psiB;
+  } else if (P.a_mag_model == RAYS_AXI_MAG_EQDSK_LIN) {  // eqdsk_magnetics_lin_interp_psi: GetPsi / PSIBOUND
+    psiN = eqlin_getpsi(P, r, z) / P.a_psiB;
   } else {
     spl2_fpp(P, r, z, f6);
     psiN = f6[0] / P.a_psiB;  // psiN = Psi/PSIBOUND (:314)

@@ -42,7 +42,9 @@ struct DevParams {
                                             // at the very end of the RHS' dependency chain, nothing hides its latency
   // axisym_toroid + eqdsk spline magnetics (axisym_toroid_eq_m.f90, eqdsk_magnetics_spline_interp_m.f90)
   int a_n_model, a_nr, a_nz, a_n_rb, a_n_ne, a_n_te, a_n_ti;
-  int a_mag_model;                          // RAYS_AXI_MAG_*: eqdsk bicubic spline | analytic Solovev field
+  int a_mag_model;                          // RAYS_AXI_MAG_*: eqdsk bicubic spline | analytic Solovev field | eqdsk bilinear
+  double a_lin_dR, a_lin_dZ;                // 'eqdsk_magnetics_lin_interp': dR, dZ of eqdsk_utilities_m (half a grid cell);
+                                            // its tables sit in a_r_grid, a_z_grid, a_psi_fspl = Psi(nr, nz), a_rb_fspl = T(nr)
   int a_t_model[RAYS_NS0];
   double a_box_rmin, a_box_rmax, a_box_zmin, a_box_zmax, a_psi_limit, a_psiB, a_inv_psiB;
   double a_an1, a_an2, a_d_scrape, a_T_scrape;
@@ -569,6 +571,87 @@ RAYS_DEV void spl1_tab(const DevParams& P, const double* grid, const double* fsp
   spl1_fp<const double*>(grid, fspl, n, x, f, fp);
 }
 
+// ---- 'eqdsk_magnetics_lin_interp': eqdsk_utilities_m.f90:144-306 + eqdsk_magnetics_lin_interp_m.f90:146-214 ----
+// GetPsi: bilinear in the cell i = 1 + int((R - R_grid(1))/(R_grid(2) - R_grid(1))), likewise j.  The reference
+// does not bound i, j: its central differences reach one cell beyond the grid for points in the outermost cells
+// and then read the neighbouring column through Fortran's storage order.  Same here (flat index); only an index
+// outside the array altogether -- undefined in the reference -- is clamped.
+RAYS_DEV double eqlin_psi_at(const DevParams& P, int i, int j) {  // Psi(i, j), 1-based
+  long long k = (long long)(i - 1) + (long long)(j - 1) * P.a_nr;
+  const long long n = (long long)P.a_nr * P.a_nz;
+  k = k < 0 ? 0 : (k >= n ? n - 1 : k);
+  return P.a_psi_fspl[k];
+}
+RAYS_DEV double eqlin_getpsi(const DevParams& P, double R, double Z) {  // :144-162
+  const double r1 = P.a_r_grid[0], z1 = P.a_z_grid[0];
+  const Recip Rhr = make_recip(P.a_r_grid[1] - r1), Rhz = make_recip(P.a_z_grid[1] - z1);
+  const int i = 1 + (int)div(R - r1, Rhr);
+  const int j = 1 + (int)div(Z - z1, Rhz);
+  const int ic = i < 1 ? 1 : (i > P.a_nr ? P.a_nr : i), jc = j < 1 ? 1 : (j > P.a_nz ? P.a_nz : j);  // (memory safety only)
+  const double x = div(R - P.a_r_grid[ic - 1], Rhr);
+  const double y = div(Z - P.a_z_grid[jc - 1], Rhz);
+  const double omx = 1. - x, omy = 1. - y;
+  return ((eqlin_psi_at(P, i, j) * omx * omy + eqlin_psi_at(P, i + 1, j) * x * omy) + eqlin_psi_at(P, i, j + 1) * omx * y) +
+         eqlin_psi_at(P, i + 1, j + 1) * x * y;
+}
+RAYS_DEV double eqlin_getrbphi(const DevParams& P, double R) {  // :168-184
+  const double r1 = P.a_r_grid[0];
+  const Recip Rhr = make_recip(P.a_r_grid[1] - r1);
+  const int i = 1 + (int)div(R - r1, Rhr);
+  const int ic = i < 1 ? 1 : (i > P.a_nr - 1 ? P.a_nr - 1 : i);  // (memory safety only: T(i), T(i+1))
+  const double x = div(R - P.a_r_grid[ic - 1], Rhr);
+  return P.a_rb_fspl[ic - 1] * (1. - x) + P.a_rb_fspl[ic] * x;
+}
+// psi, dPsi/dR, dPsi/dZ by the reference's differences (GetPsiR :190-204, GetPsiZ :210-223)
+RAYS_DEV void eqlin_psi_grad(const DevParams& P, double R, double Z, double& psi, double& PsiR, double& PsiZ) {
+  const double dR = P.a_lin_dR, dZ = P.a_lin_dZ;
+  psi = eqlin_getpsi(P, R, Z);
+  PsiR = (eqlin_getpsi(P, R + dR, Z) - eqlin_getpsi(P, R - dR, Z)) / 2. / dR;
+  PsiZ = (eqlin_getpsi(P, R, Z + dZ) - eqlin_getpsi(P, R, Z - dZ)) / 2. / dZ;
+}
+// eqdsk_magnetics_lin_interp (eqdsk_magnetics_lin_interp_m.f90:146-214)
+RAYS_DEV void eqlin_magnetics(const DevParams& P, double x, double y, double z, double r, double bvec[3],
+                              double gbt[3][3], double& psiN, double gradpsiN[3]) {
+  const double dR = P.a_lin_dR, dZ = P.a_lin_dZ;
+  double psi, PsiR, PsiZ;
+  eqlin_psi_grad(P, r, z, psi, PsiR, PsiZ);
+  const Recip Rr = make_recip(r), Rr2 = make_recip(sq(r));
+  const Recip RpsiB = const_recip(P.a_psiB, P.a_inv_psiB);
+  const double br = div(-PsiZ, Rr);                            // :174
+  const double bz = div(PsiR, Rr);                             // :175
+  const double bphi = div(eqlin_getrbphi(P, r), Rr);           // :176
+  const double gradpsi[3] = {x * bz, y * bz, -r * br};         // :178
+  psiN = div(psi, RpsiB);
+  gradpsiN[0] = div(gradpsi[0], RpsiB);
+  gradpsiN[1] = div(gradpsi[1], RpsiB);
+  gradpsiN[2] = div(gradpsi[2], RpsiB);
+  // GetPsiRZ (:271-287), GetPsiZZ (:251-265), GetPsiRR (:229-245), GetRBphiR (:293-306)
+  const double PsiRZ = (((eqlin_getpsi(P, r + dR, z + dZ) - eqlin_getpsi(P, r - dR, z + dZ)) - eqlin_getpsi(P, r + dR, z - dZ)) +
+                        eqlin_getpsi(P, r - dR, z - dZ)) / 4. / dR / dZ;
+  const double PsiZZ = ((eqlin_getpsi(P, r, z + 2. * dZ) - 2. * psi) + eqlin_getpsi(P, r, z - 2. * dZ)) / dZ / dZ;
+  const double PsiRR = ((eqlin_getpsi(P, r + 2. * dR, z) - 2. * psi) + eqlin_getpsi(P, r - 2. * dR, z)) / dR / dR;
+  const double RBphiR = (eqlin_getrbphi(P, r + dR) - eqlin_getrbphi(P, r - dR)) / 2. / dR;
+  const double br_r = div(br, Rr), bphi_r = div(bphi, Rr);
+  const double dbrdr = -br_r - div(PsiRZ, Rr);                 // :184
+  const double dbrdz = div(-PsiZZ, Rr);                        // :185
+  const double dbzdr = div(-bz, Rr) + div(PsiRR, Rr);          // :186
+  const double dbzdz = div(PsiRZ, Rr);                         // :187
+  const double dbphidr = div(RBphiR - bphi, Rr);               // :188
+  bvec[0] = div(br * x, Rr) - div(bphi * y, Rr);
+  bvec[1] = div(br * y, Rr) + div(bphi * x, Rr);
+  bvec[2] = bz;
+  const double x2 = sq(x), y2 = sq(y);
+  gbt[0][0] = div(dbrdr * x2 + div(br * y2, Rr) + (-dbphidr + bphi_r) * x * y, Rr2);
+  gbt[1][0] = div((dbrdr - br_r) * x * y - dbphidr * y2 - div(bphi * x2, Rr), Rr2);
+  gbt[2][0] = div(dbrdz * x, Rr);
+  gbt[0][1] = div((dbrdr - br_r) * x * y + dbphidr * x2 + div(bphi * y2, Rr), Rr2);
+  gbt[1][1] = div(dbrdr * y2 + div(br * x2, Rr) + (dbphidr - bphi_r) * x * y, Rr2);
+  gbt[2][1] = div(dbrdz * y, Rr);
+  gbt[0][2] = div(dbzdr * x, Rr);
+  gbt[1][2] = div(dbzdr * y, Rr);
+  gbt[2][2] = dbzdz;
+}
+
 // axisym_toroid_eq + eqdsk_magnetics_spline_interp
 //   axisym_toroid_eq_m.f90:215-362, eqdsk_magnetics_spline_interp_m.f90:206-282,
 //   density_spline_interp_m.f90:109-130, temperature_spline_interp_m.f90
@@ -596,6 +679,8 @@ RAYS_DEV int axisym_fields(const DevParams& P, const double rvec[3], double bvec
       err = merr;
     }
     solovev_magnetics(P, x, y, z, r, bvec, gbt, psiN, gpN);
+  } else if (P.a_mag_model == RAYS_AXI_MAG_EQDSK_LIN) {  // wave-uniform
+    eqlin_magnetics(P, x, y, z, r, bvec, gbt, psiN, gpN);
   } else {
     double f6[6], RBphi, RBphiR;
     spl2_fpp(P, r, z, f6);

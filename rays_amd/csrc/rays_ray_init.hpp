@@ -112,6 +112,14 @@ RAYS_DEV void launch_gradpsi(const DevParams& P, const double rvec[3], double g[
     g[0] = x * bz;
     g[1] = y * bz;
     g[2] = -r * br;
+  } else if (P.a_mag_model == RAYS_AXI_MAG_EQDSK_LIN) {  // eqdsk_magnetics_lin_interp_psi (:216-249)
+    double psi, PsiR, PsiZ;
+    eqlin_psi_grad(P, r, z, psi, PsiR, PsiZ);
+    const Recip Rr = make_recip(r);
+    const double br = div(-PsiZ, Rr), bz = div(PsiR, Rr);
+    g[0] = x * bz;
+    g[1] = y * bz;
+    g[2] = -r * br;
   } else {
     double f6[6];
     spl2_fpp(P, r, z, f6);

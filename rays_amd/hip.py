@@ -25,7 +25,7 @@ LIB_PATH = os.environ.get("RAYS_HIP_LIB") or os.path.join(_HERE, "lib", "librays
 # every symbol include/rays_hip.h declares
 EXPORTED_SYMBOLS = (
     "rays_hip_init", "rays_hip_init_devices", "rays_hip_finalize", "rays_hip_device_count", "rays_hip_sizeof_params",
-    "rays_hip_last_error", "rays_hip_set_zfun_table", "rays_hip_set_axisym_tables",
+    "rays_hip_last_error", "rays_hip_set_zfun_table", "rays_hip_set_axisym_tables", "rays_hip_set_eqdsk_lin_tables",
     "rays_hip_stop_flag_text", "rays_hip_check_params", "rays_hip_trace", "rays_hip_trace_gather", "rays_hip_result_to_host", "rays_hip_trace_device", "rays_hip_scan_device", "rays_hip_ode_step_device",
     "rays_hip_kernel_name", "rays_hip_kernel_name_for", "rays_hip_probe", "rays_hip_pack_device", "rays_hip_unpack_device",
     "rays_hip_sizeof_fan", "rays_hip_ray_init", "rays_hip_ray_init_device",
@@ -68,6 +68,8 @@ def load():
     lib.rays_hip_set_zfun_table.argtypes = [dp, C.c_int, C.c_double, C.c_double]
     lib.rays_hip_set_axisym_tables.restype = C.c_int
     lib.rays_hip_set_axisym_tables.argtypes = [C.POINTER(AxisymTables)]
+    lib.rays_hip_set_eqdsk_lin_tables.restype = C.c_int
+    lib.rays_hip_set_eqdsk_lin_tables.argtypes = [C.POINTER(AxisymTables), C.c_double, C.c_double]
     lib.rays_hip_check_params.restype = C.c_int
     lib.rays_hip_check_params.argtypes = [pp]
     lib.rays_hip_kernel_name.restype = C.c_char_p
@@ -145,6 +147,10 @@ def set_zfun_table(fspl_re=None, x_min=None, x_max=None):
 def set_axisym_tables(tab: dict):
     """Hand the host-built spline tables of an eqdsk equilibrium to the library (copied)."""
     t, keep = axisym_tables_struct(tab)
+    if "lin_psi" in tab:   # magnetics_model = 'eqdsk_magnetics_lin_interp'
+        _check(load().rays_hip_set_eqdsk_lin_tables(C.byref(t), float(tab["lin_dR"]), float(tab["lin_dZ"])),
+               "rays_hip_set_eqdsk_lin_tables")
+        return
     _check(load().rays_hip_set_axisym_tables(C.byref(t)), "rays_hip_set_axisym_tables")
 
 

@@ -22,7 +22,7 @@ ODE = {"RK4_ODE": 0, "SG_ODE": 1}
 DERIV = {"cold": 0, "numerical": 1}
 RAY_PARAM = {"arcl": 0, "time": 1}
 EQUILIB = {"slab": 0, "solovev": 1, "axisym_toroid": 2}
-AXI_MAGNETICS = {"eqdsk_magnetics_spline_interp": 0, "solovev_magnetics": 1}
+AXI_MAGNETICS = {"eqdsk_magnetics_spline_interp": 0, "solovev_magnetics": 1, "eqdsk_magnetics_lin_interp": 2}
 AXI_N = {"constant": 0, "parabolic": 1, "density_spline_interp": 2}
 AXI_T = {"zero": 0, "constant": 1, "parabolic": 2, "temperature_spline_interp": 3}
 SLAB_BX = {"zero": 0}
@@ -137,9 +137,16 @@ def axisym_tables_struct(tab: Dict[str, Any]):
         return len(a)
 
     t.nr, t.nz = put("r_grid"), put("z_grid")
-    put("psi_fspl")
-    t.n_rb = put("rb_grid")
-    put("rb_fspl")
+    if "lin_psi" in tab:   # 'eqdsk_magnetics_lin_interp' (rays_hip_set_eqdsk_lin_tables): raw Psi(nr, nz), T(nr)
+        for src, dst in (("lin_psi", "psi_fspl"), ("lin_t", "rb_fspl")):
+            a = np.ascontiguousarray(tab[src], dtype=np.float64)
+            keep.append(a)
+            setattr(t, dst, a.ctypes.data_as(C.POINTER(C.c_double)))
+        t.n_rb = t.nr
+    else:
+        put("psi_fspl")
+        t.n_rb = put("rb_grid")
+        put("rb_fspl")
     t.n_ne = put("ne_grid")
     put("ne_fspl")
     t.n_te = put("te_grid")

@@ -434,7 +434,7 @@ def initialize_ray_init(p: RaysParams, nml: Dict[str, Dict[str, Any]], axisym_ta
     if model == "solovev":
         return ray_init_solovev_nphi_ntheta(p, nml)
     if model == "axisym_toroid_ray_init_R_Z_nphi_ntheta":
-        if p.axisym.magnetics_model == 1:   # 'solovev_magnetics': no host mirror; the device launcher is the product's
+        if p.axisym.magnetics_model != 0:   # 'solovev_magnetics', 'eqdsk_magnetics_lin_interp': no host mirror; the device launcher is the product's
             from . import hip
             fan, nray_max = fan_from_namelist(nml)
             return hip.ray_init_host(p, fan, nray_max)

@@ -60,8 +60,20 @@ def load_axisym_tables(namelist_path: str, nml: Dict[str, Dict[str, Any]]) -> Op
         return None
     if str(nml.get("axisym_toroid_eq_list", {}).get("magnetics_model", "")).strip() == "solovev_magnetics":
         return None   # analytic magnetics: nothing to load (spline PROFILE models would still need their tables)
+    here = os.path.dirname(os.path.abspath(namelist_path))
+    if str(nml.get("axisym_toroid_eq_list", {}).get("magnetics_model", "")).strip() == "eqdsk_magnetics_lin_interp":
+        # bilinear eqdsk model: no spline fit, the host mirror reads the g-eqdsk itself (rays_amd/eqdsk.py); splined
+        # PROFILES still come from the RAYS host's tables file when there is one
+        from .eqdsk import eqdsk_lin_tables
+        eq = str(nml.get("eqdsk_magnetics_lin_interp_list", {}).get("eqdsk_file_name", "")).strip()
+        tab = eqdsk_lin_tables(os.path.join(here, eq))
+        f = os.path.join(here, eq + ".tables.npz")
+        if os.path.exists(f):
+            z = np.load(f)
+            tab.update({k: z[k] for k in z.files if k[:3] in ("ne_", "te_", "ti_")})
+        return tab
     eq = str(nml.get("eqdsk_magnetics_spline_interp_list", {}).get("eqdsk_file_name", "")).strip()
-    f = os.path.join(os.path.dirname(os.path.abspath(namelist_path)), eq + ".tables.npz")
+    f = os.path.join(here, eq + ".tables.npz")
     if not os.path.exists(f):
         raise FileNotFoundError(f"{f}: spline tables of the eqdsk equilibrium (built by the RAYS host)")
     z = np.load(f)

@@ -19,7 +19,8 @@ GOLDEN_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_n
                 "gold_slab_ns1_rk4", "gold_solovev64_damp_grad_rk4", "gold_slab_6spec_sg", "gold_solovev64_4spec_rk4_num",
                 "gold_solovev64_damp_multi_sg", "gold_slab16_damp_multi_grad_rk4",
                 "gold_axisym64_solmag_damp_rk4", "gold_axisym64_solmag_sg_num",
-                "gold_axisym64_solmag_splines_grad_rk4"]
+                "gold_axisym64_solmag_splines_grad_rk4",
+                "gold_axisym64_eqlin_damp_rk4", "gold_axisym64_eqlin_tspline_sg_num"]
 
 
 def load_golden(name):
@@ -28,7 +29,7 @@ def load_golden(name):
     tab = {k[4:]: (float(g[k]) if g[k].ndim == 0 else g[k]) for k in g.files if k.startswith("axi_")}
     # eqdsk equilibrium (or an analytic magnetics model with splined profiles): hand the host-built spline tables
     # to every implementation under test
-    if any(np.size(tab.get(k, ())) for k in ("r_grid", "ne_grid", "te_grid", "ti_grid")):
+    if any(np.size(tab.get(k, ())) for k in ("r_grid", "ne_grid", "te_grid", "ti_grid")):   # ("lin_psi": bilinear eqdsk model)
         from rays_amd import hip
         from tests import emul_lib, oracle_lib
 

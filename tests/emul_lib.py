@@ -90,8 +90,9 @@ def set_axisym_tables(tab: dict, small_tiers: bool = False):
     t, keep = axisym_tables_struct(tab)
     fn = (tiers_lib() if small_tiers else lib()).rays_emul_set_axisym_tables
     fn.restype = C.c_int
-    fn.argtypes = [C.POINTER(AxisymTables)]
-    fn(C.byref(t))
+    fn.argtypes = [C.POINTER(AxisymTables), C.c_int, C.c_double, C.c_double]
+    lin = "lin_psi" in tab   # 'eqdsk_magnetics_lin_interp'
+    fn(C.byref(t), int(lin), float(tab["lin_dR"]) if lin else 0.0, float(tab["lin_dZ"]) if lin else 0.0)
 
 
 def _offset_zeros(shape, offset):

@@ -78,6 +78,8 @@ CASES = [
     ("gold_axisym64_solmag_damp_rk4", "gold_axisym64_solmag_damp_rk4.in", list(range(0, 64, 5)), 10, 60),
     ("gold_axisym64_solmag_sg_num", "gold_axisym64_solmag_sg_num.in", list(range(0, 64, 7)), 0, 0),
     ("gold_axisym64_solmag_splines_grad_rk4", "gold_axisym64_solmag_splines_grad_rk4.in", list(range(0, 64, 9)), 25, 0),
+    ("gold_axisym64_eqlin_damp_rk4", "gold_axisym64_eqlin_damp_rk4.in", list(range(0, 64, 5)), 10, 0),
+    ("gold_axisym64_eqlin_tspline_sg_num", "gold_axisym64_eqlin_tspline_sg_num.in", list(range(0, 64, 7)), 0, 0),
 ]
 
 
@@ -155,7 +157,7 @@ def main():
             host_tabs = {k: np.asarray(v) for k, v in axi.items()}
             if dep is not None and "rho_grid" in dep:   # rho(psiN) spline, for the Ptotal_rho profile
                 host_tabs.update(rho_grid=dep["rho_grid"], rho_fspl=dep["rho_fspl"])
-            if len(axi["r_grid"]):                      # (an analytic magnetics model has profile tables only)
+            if len(axi["r_grid"]) and "psi_fspl" in axi:   # (analytic magnetics: profile tables only; bilinear: Python reads the eqdsk)
                 np.savez_compressed(os.path.join(ROOT, "configs", "solovev_65x65.geqdsk.tables.npz"), **host_tabs)
         if dep is not None:
             # deposition profiles of the FULL fan + the full-fan trajectories they

@@ -60,10 +60,14 @@ extern "C" int rays_emul_set_zfun_table(const double* f, int nx, double x_min, d
 
 static std::vector<double> g_axi[11];
 static int g_axi_n[6];
-extern "C" int rays_emul_set_axisym_tables(const rays_axisym_tables_t* t) {
+static int g_axi_lin = 0;
+static double g_axi_dR = 0., g_axi_dZ = 0.;
+extern "C" int rays_emul_set_axisym_tables(const rays_axisym_tables_t* t, int lin, double dR, double dZ) {
+  g_axi_lin = lin; g_axi_dR = dR; g_axi_dZ = dZ;
   const double* src[11] = {t->r_grid, t->z_grid, t->psi_fspl, t->rb_grid, t->rb_fspl, t->ne_grid, t->ne_fspl,
                            t->te_grid, t->te_fspl, t->ti_grid, t->ti_fspl};
-  const size_t len[11] = {(size_t)t->nr, (size_t)t->nz, (size_t)16 * t->nr * t->nz, (size_t)t->n_rb, (size_t)4 * t->n_rb,
+  const size_t len[11] = {(size_t)t->nr, (size_t)t->nz, (size_t)(lin ? 1 : 16) * t->nr * t->nz, lin ? (size_t)0 : (size_t)t->n_rb,
+                          (size_t)(lin ? 1 : 4) * t->n_rb,
                           (size_t)t->n_ne, (size_t)4 * t->n_ne, (size_t)t->n_te, (size_t)4 * t->n_te,
                           (size_t)t->n_ti, (size_t)4 * t->n_ti};
   for (int k = 0; k < 11; k++) g_axi[k].assign(src[k] ? src[k] : nullptr, src[k] ? src[k] + len[k] : nullptr);
@@ -104,7 +108,9 @@ extern "C" int rays_emul_trace_ex(const rays_params_t* p, int nray, const double
     D.zf_fspl = g_zfun.data(); D.zf_nx = g_zf_nx; D.zf_xmin = g_zf_xmin; D.zf_xmax = g_zf_xmax;
   }
   if (p->equilib_model == RAYS_EQ_AXISYM) {
-    if (p->axisym.magnetics_model == RAYS_AXI_MAG_EQDSK_SPLINE && g_axi[2].empty()) return 3;
+    if (p->axisym.magnetics_model == RAYS_AXI_MAG_EQDSK_SPLINE && (g_axi[2].empty() || g_axi_lin)) return 3;
+    if (p->axisym.magnetics_model == RAYS_AXI_MAG_EQDSK_LIN && (g_axi[2].empty() || !g_axi_lin)) return 3;
+    D.a_lin_dR = g_axi_dR; D.a_lin_dZ = g_axi_dZ;
     D.a_nr = g_axi_n[0]; D.a_nz = g_axi_n[1]; D.a_n_rb = g_axi_n[2]; D.a_n_ne = g_axi_n[3]; D.a_n_te = g_axi_n[4]; D.a_n_ti = g_axi_n[5];
     D.a_r_grid = g_axi[0].data(); D.a_z_grid = g_axi[1].data(); D.a_psi_fspl = g_axi[2].data();
     D.a_rb_grid = g_axi[3].data(); D.a_rb_fspl = g_axi[4].data(); D.a_ne_grid = g_axi[5].data(); D.a_ne_fspl = g_axi[6].data();
@@ -151,7 +157,9 @@ extern "C" int rays_emul_ray_init(const rays_params_t* p, const rays_fan_t* fan,
   F.launch = launch.data();
   rays::DevParams D = make_dev_params(*p);
   if (p->equilib_model == RAYS_EQ_AXISYM) {
-    if (p->axisym.magnetics_model == RAYS_AXI_MAG_EQDSK_SPLINE && g_axi[2].empty()) return 3;
+    if (p->axisym.magnetics_model == RAYS_AXI_MAG_EQDSK_SPLINE && (g_axi[2].empty() || g_axi_lin)) return 3;
+    if (p->axisym.magnetics_model == RAYS_AXI_MAG_EQDSK_LIN && (g_axi[2].empty() || !g_axi_lin)) return 3;
+    D.a_lin_dR = g_axi_dR; D.a_lin_dZ = g_axi_dZ;
     D.a_nr = g_axi_n[0]; D.a_nz = g_axi_n[1]; D.a_n_rb = g_axi_n[2]; D.a_n_ne = g_axi_n[3]; D.a_n_te = g_axi_n[4]; D.a_n_ti = g_axi_n[5];
     D.a_r_grid = g_axi[0].data(); D.a_z_grid = g_axi[1].data(); D.a_psi_fspl = g_axi[2].data();
     D.a_rb_grid = g_axi[3].data(); D.a_rb_fspl = g_axi[4].data(); D.a_ne_grid = g_axi[5].data(); D.a_ne_fspl = g_axi[6].data();
@@ -180,7 +188,9 @@ extern "C" int rays_emul_deposition(const rays_params_t* p, int which, int n_bin
   rays::DevParams D = make_dev_params(*p);
   if (which != 2) {
     if (p->equilib_model != RAYS_EQ_AXISYM) return 3;
-    if (p->axisym.magnetics_model == RAYS_AXI_MAG_EQDSK_SPLINE && g_axi[2].empty()) return 3;
+    if (p->axisym.magnetics_model == RAYS_AXI_MAG_EQDSK_SPLINE && (g_axi[2].empty() || g_axi_lin)) return 3;
+    if (p->axisym.magnetics_model == RAYS_AXI_MAG_EQDSK_LIN && (g_axi[2].empty() || !g_axi_lin)) return 3;
+    D.a_lin_dR = g_axi_dR; D.a_lin_dZ = g_axi_dZ;
     D.a_nr = g_axi_n[0]; D.a_nz = g_axi_n[1]; D.a_n_rb = g_axi_n[2];
     D.a_r_grid = g_axi[0].data(); D.a_z_grid = g_axi[1].data(); D.a_psi_fspl = g_axi[2].data();
     D.a_rb_grid = g_axi[3].data(); D.a_rb_fspl = g_axi[4].data();

@@ -58,6 +58,9 @@ def _ip(a):
 
 def set_axisym_tables(tab: dict):
     t, keep = axisym_tables_struct(tab)
+    if "lin_psi" in tab:
+        lib().rays_oracle_set_eqdsk_lin_tables(C.byref(t), C.c_double(float(tab["lin_dR"])), C.c_double(float(tab["lin_dZ"])))
+        return
     lib().rays_oracle_set_axisym_tables(C.byref(t))
 
 

@@ -66,9 +66,15 @@ def read_axisym_tables(path: str) -> dict:
         off += 8 * n
         return a
 
-    out["r_grid"], out["z_grid"] = take(nr), take(nz)
-    out["psi_fspl"] = take(16 * nr * nz)          # fspl(4,4,nr,nz) Fortran order
-    out["rb_grid"], out["rb_fspl"] = take(n_rb), take(4 * n_rb)
+    if n_rb == -1:   # 'eqdsk_magnetics_lin_interp': eqdsk_utilities_m's dR, dZ, R_grid, Z_grid, Psi(nr, nz), T(nr)
+        out["lin_dR"], out["lin_dZ"] = (float(v) for v in take(2))
+        out["r_grid"], out["z_grid"] = take(nr), take(nz)
+        out["lin_psi"] = take(nr * nz)            # Psi(nr, nz) Fortran order, PSIAXIS subtracted
+        out["lin_t"] = take(nr)
+    else:
+        out["r_grid"], out["z_grid"] = take(nr), take(nz)
+        out["psi_fspl"] = take(16 * nr * nz)          # fspl(4,4,nr,nz) Fortran order
+        out["rb_grid"], out["rb_fspl"] = take(n_rb), take(4 * n_rb)
     for key, n in (("ne", n_ne), ("te", n_te), ("ti", n_ti)):
         if n:
             out[key + "_grid"], out[key + "_fspl"] = take(n), take(4 * n)

@@ -45,8 +45,8 @@ def test_module_state_equals_reference(name):
 def test_ray_init_equals_reference(name):
     """simple_slab / solovev n_theta x n_phi launchers: same rays, same order, same bits."""
     g, nml, p = load_golden(name)
-    if p.equilib_model == 2 and p.axisym.magnetics_model == 1:
-        pytest.skip("'solovev_magnetics' has no Python host mirror: its fan comes from the device launcher "
+    if p.equilib_model == 2 and p.axisym.magnetics_model != 0:
+        pytest.skip("'solovev_magnetics' / 'eqdsk_magnetics_lin_interp' have no Python host mirror: the fan comes from the device launcher "
                     "(test_cpu_kernel_emul.py::test_ray_init_source_on_host_equals_reference, test_gpu_parity.py)")
     tab = {k[4:]: (float(g[k]) if g[k].ndim == 0 else g[k]) for k in g.files if k.startswith("axi_")}
     r0, n0, _ = initialize_ray_init(p, nml, tab or None)
@@ -182,3 +182,19 @@ def test_bench_gpus_n_is_never_a_silent_one_gpu_run():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "must start exactly --gpus ranks" in (r.stderr + r.stdout)
+
+
+def test_eqdsk_reader_builds_the_reference_lin_interp_tables():
+    """rays_amd/eqdsk.py (ReadgFile + initialize_eqdsk_magnetics_lin_interp restated for the Python host): grids, dR,
+    dZ, Psi - PSIAXIS, T, box and psiB equal the reference's eqdsk_utilities_m arrays (dumped into the fixture) bit for
+    bit, and RaysRun-style loading yields the fixture's parameters."""
+    from rays_amd.eqdsk import eqdsk_lin_tables
+    g, nml, p = load_golden("gold_axisym64_eqlin_damp_rk4")
+    t = eqdsk_lin_tables(os.path.join(ROOT, "configs", "solovev_65x65.geqdsk"))
+    for k in ("r_grid", "z_grid", "lin_psi", "lin_t", "lin_dR", "lin_dZ", "box_rmin", "box_rmax", "box_zmin", "box_zmax", "psiB"):
+        np.testing.assert_array_equal(np.asarray(t[k]), np.asarray(g["axi_" + k]), err_msg=k)
+    from rays_amd.trace import load_axisym_tables
+    tab = load_axisym_tables(os.path.join(ROOT, "configs", str(g["config"])), nml)
+    np.testing.assert_array_equal(tab["ne_fspl"], g["axi_ne_fspl"])     # the splined density rides along from the tables file
+    q = params_from_namelist(nml, tab)
+    assert bytes(q) == bytes(p)

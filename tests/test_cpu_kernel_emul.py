@@ -105,12 +105,14 @@ def test_deposition_source_on_host_equals_reference():
         assert q == g["dep_q_sum"][which]
 
 
-def test_solovev_magnetics_deposition_source_on_host_equals_reference():
+@pytest.mark.parametrize("name", ["gold_axisym64_solmag_damp_rk4", "gold_axisym64_eqlin_damp_rk4"])
+def test_other_magnetics_deposition_source_on_host_equals_reference(name):
     """'Ptotal_psi' of an axisym_toroid run with magnetics_model = 'solovev_magnetics' (axisym_toroid_psi ->
-    solovev_magnetics_psi, solovev_magnetics_m.f90:199-244): work, profile and Q_sum bit for bit.  ('Ptotal_rho'
-    does not exist for this magnetics model in the reference, axisym_toroid_eq_m.f90:398-430.)"""
+    solovev_magnetics_psi, solovev_magnetics_m.f90:199-244) or 'eqdsk_magnetics_lin_interp'
+    (eqdsk_magnetics_lin_interp_psi: GetPsi / PSIBOUND): work, profile and Q_sum bit for bit.  ('Ptotal_rho'
+    does not exist for these magnetics models in the reference, axisym_toroid_eq_m.f90:398-430.)"""
     from tests.common import padded_full_trajectories
-    g, nml, p = load_golden("gold_axisym64_solmag_damp_rk4")
+    g, nml, p = load_golden(name)
     assert [str(n) for n in g["dep_names"]] == ["Ptotal_psi"]
     rv = padded_full_trajectories(g, p)
     work, prof = emul_lib.deposition(p, 0, int(g["dep_n_bins"]), rv, g["npoints_full"], g["dep_power"],
@@ -178,3 +180,24 @@ def test_one_step_restart_reproduces_the_next_reference_point(name):
     got, resid, code = emul_lib.ode_step(p, v0, s0)
     assert (code == 0).all()
     np.testing.assert_array_equal(got, v1)
+
+
+def test_eqdsk_lin_interp_outermost_cells_are_memory_safe():
+    """GetPsi does not bound its cell index (eqdsk_utilities_m.f90:152-153): the central differences of a point in
+    the outermost cells reach one cell beyond R_grid / Z_grid, where the reference reads the neighbouring column of
+    Psi through the storage order and, past the last row, memory outside the array.  The kernel source and the C
+    restatement follow the storage order and clamp only what leaves the array: same results, no fault, at the four
+    corners and edge midpoints of the box."""
+    from tests import oracle_lib
+    g, nml, p = load_golden("gold_axisym64_eqlin_damp_rk4")
+    a = p.axisym
+    eps = 1e-4
+    pts = [(r, z) for r in (a.box_rmin + eps, 0.5 * (a.box_rmin + a.box_rmax), a.box_rmax - eps)
+           for z in (a.box_zmin + eps, 0.0, a.box_zmax - eps)]
+    r0 = np.array([[r, 0.0, z] for r, z in pts])
+    n0 = np.tile(g["rindex_vec0"][0], (len(pts), 1))
+    ora = oracle_lib.trace(p, r0, n0)
+    out = emul_lib.trace(p, r0, n0)
+    for k in ("ray_vec", "residual", "npoints", "stop_code", "end_ray_vec"):
+        np.testing.assert_array_equal(out[k], ora[k])
+    assert (ora["npoints"] >= 1).all()

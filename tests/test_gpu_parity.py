@@ -22,11 +22,11 @@ RK4_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_num"
              "gold_slab_negative_dens_rk4", "gold_slab16_damp_rk4",
              "gold_slab_ns1_rk4", "gold_solovev64_damp_grad_rk4", "gold_solovev64_4spec_rk4_num",
              "gold_slab16_damp_multi_grad_rk4", "gold_axisym64_solmag_damp_rk4",
-             "gold_axisym64_solmag_splines_grad_rk4"]
+             "gold_axisym64_solmag_splines_grad_rk4", "gold_axisym64_eqlin_damp_rk4"]
 SG_CASES = ["gold_solovev64_sg_cold", "gold_solovev64_sg_num", "gold_solovev64_damp_sg", "gold_axisym64_eqdsk_damp_sg",
             "gold_solovev64_arcl_grad_sg", "gold_solovev64_slow_sg",
             "gold_slab_shear_gauss_3spec_sg_num", "gold_slab_6spec_sg", "gold_solovev64_damp_multi_sg",
-            "gold_axisym64_solmag_sg_num"]
+            "gold_axisym64_solmag_sg_num", "gold_axisym64_eqlin_tspline_sg_num"]
 
 @pytest.mark.parametrize("name", RK4_CASES)
 def test_rk4_matches_reference_golden(name):
@@ -156,10 +156,12 @@ def test_device_deposition_profiles_match_reference():
         np.testing.assert_array_equal(tot.cpu().numpy(), g["dep_profile"][which])
 
 
-def test_device_solovev_magnetics_deposition_profile_matches_reference():
-    """'Ptotal_psi' of an axisym_toroid run with the analytic 'solovev_magnetics' field: the host entry
-    rays_hip_deposition on the device trace's arrays equals the reference post-processor bit for bit."""
-    g, nml, p = load_golden("gold_axisym64_solmag_damp_rk4")
+@pytest.mark.parametrize("name", ["gold_axisym64_solmag_damp_rk4", "gold_axisym64_eqlin_damp_rk4"])
+def test_device_other_magnetics_deposition_profile_matches_reference(name):
+    """'Ptotal_psi' of an axisym_toroid run with the analytic 'solovev_magnetics' field / the bilinear
+    'eqdsk_magnetics_lin_interp' model: the host entry rays_hip_deposition on the device trace's arrays equals the
+    reference post-processor bit for bit ('Ptotal_rho' does not exist for these models in the reference)."""
+    g, nml, p = load_golden(name)
     out = hip.trace_host(p, g["rvec0_full"], g["rindex_vec0_full"], ngpu=1)
     np.testing.assert_array_equal(out["npoints"], g["npoints_full"])
     work, prof = hip.deposition_host(p, "Ptotal_psi", int(g["dep_n_bins"]), out["ray_vec"], out["npoints"], g["dep_power"])
