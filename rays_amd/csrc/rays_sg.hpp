@@ -533,6 +533,12 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
 #pragma unroll
     for (int l = 0; l < NV; l++) win[l] = pc == PC_F2 ? pp[l] : yy[l];
     SG_PROF(1);  // init + phase vote
+#ifdef RAYS_SG_PROFILE
+    prof_acc[25] += __popcll(__ballot(act));              // lanes served by this trip's RHS
+    prof_acc[26] += 1;                                    // trips
+    prof_acc[27] += __popcll(__ballot(alive));            // lanes that hold a ray
+    prof_acc[28] += __popcll(__ballot(alive && at_check && !act));  // lanes waiting for their wave at an interval end
+#endif
     if (act) rhs_eval<EQ, NS, DERIV, NV>(P, win, pc == PC_CHECK, resid, cs_flag, cs_stop, code, f);
 #ifdef RAYS_SG_PROFILE
     SG_PROF(__popcll(__ballot(act)) <= 8 ? 15 : 2);  // RHS (slot 15: trips serving <= 8 lanes)

@@ -23,6 +23,10 @@ for cfg, sym in (("configs/cfg5_axisym256k_sg_damp.in", "rays_debug_sg_profile_1
     fn(out, 1)
     v = np.array(list(out)[:32], dtype=np.float64); tot = v.sum()
     print(f"{os.path.basename(cfg)}: {e0.elapsed_time(e1):.1f} ms, {hip.kernel_name(p)}; wave-clock share per section:")
+    trips = v[26]
+    print(f"   lanes served per trip {v[25] / trips:.1f} of {v[27] / trips:.1f} holding a ray; waiting at an interval end {v[28] / trips:.1f}")
+    v[25:29] = 0.0
+    tot = v.sum()
     for n, x in zip(NAMES, v):
         if not n:
             continue
