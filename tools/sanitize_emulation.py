@@ -22,6 +22,9 @@ for name in GOLDEN_CASES:
     out = emul_lib.trace(p, g["rvec0"], g["rindex_vec0"])
     assert_matches_golden(out, g, p, exact=True)
     if p.ode_solver == 1:
+        tab = {k[4:]: (float(g[k]) if g[k].ndim == 0 else g[k]) for k in g.files if k.startswith("axi_")}
+        if any(np.size(tab.get(k, ())) for k in ("r_grid", "ne_grid", "te_grid", "ti_grid")):
+            emul_lib.set_axisym_tables(tab, small_tiers=True)   # (the shrunken-tier build keeps its own copy)
         out = emul_lib.trace(p, g["rvec0_full"], g["rindex_vec0_full"], small_tiers=True)
         assert np.array_equal(out["npoints"], g["npoints_full"])
     fan, nmax = fan_from_namelist(nml)
@@ -34,3 +37,11 @@ for w in (0, 1):
     work, prof = emul_lib.deposition(p, w, int(g["dep_n_bins"]), rv, g["npoints_full"], g["dep_power"], g["dep_rho_grid"], g["dep_rho_fspl"])
     assert np.array_equal(prof, g["dep_profile"][w])
 print("sanitized emulation run: all ok")
+# the bilinear eqdsk model at the corners and edges of its grid (GetPsi's unbounded cell index, rays_device.hpp)
+g, nml, p = load_golden("gold_axisym64_eqlin_damp_rk4")
+a = p.axisym
+pts = [(r, z) for r in (a.box_rmin + 1e-4, 0.5 * (a.box_rmin + a.box_rmax), a.box_rmax - 1e-4, a.box_rmax, a.box_rmin)
+       for z in (a.box_zmin + 1e-4, 0.0, a.box_zmax - 1e-4, a.box_zmax, a.box_zmin)]
+r0 = np.array([[r, 0.0, z] for r, z in pts])
+out = emul_lib.trace(p, r0, np.tile(g["rindex_vec0"][0], (len(pts), 1)))
+print("eqdsk_magnetics_lin_interp edge cells: ok", out["stop_code"].tolist())
