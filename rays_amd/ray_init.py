@@ -23,7 +23,7 @@ from typing import Any, Dict, Tuple
 import numpy as np
 
 from .params import (EQUILIB, RAY_INIT, WAVE_MODE, ConfigError, RaysFan, RaysParams, SLAB_BY, SLAB_BZ, SLAB_N,
-                     SOLOVEV_N)
+                     SOLOVEV_N, _arr)
 
 
 # ---- launch-point equilibrium (host, scalar) ----------------------------------------------------
@@ -426,9 +426,112 @@ def ray_init_axisym_toroid_R_Z_nphi_ntheta(p: RaysParams, nml: Dict[str, Dict[st
     return rvec0, rindex_vec0, np.full(n, 1.0) / n
 
 
-def initialize_ray_init(p: RaysParams, nml: Dict[str, Dict[str, Any]], axisym_tables=None):
-    """ray_init_m.f90:72-127 dispatch on ray_init_model."""
+# ---- single rays given by position and direction -------------------------------------------------
+def solve_cold_nsq_vs_theta(alpha, gamma, theta: float):
+    """nsq(1:4) = plus, minus, fast, slow roots of the cold dispersion relation at angle theta to B
+    (disp_solve_cold_nsq_vs_theta.f90:1-71; real arithmetic).  None where the reference returns with nsq unset."""
+    S, D, P, R, L = _rlsdp_cold(alpha, gamma)
+    c = math.cos(theta)
+    cos2 = c * c
+    sin2 = 1.0 - cos2
+    a = S * sin2 + P * cos2
+    b = -(R * L * sin2) - P * S * (1.0 + cos2)
+    cc = P * R * L
+    discr = b * b - 4.0 * a * cc
+    if discr < 0.0:
+        return None
+    sd = math.sqrt(discr)
+    if math.copysign(1.0, b) < 0.0:
+        plus = (-b + sd) / (2.0 * a)
+        minus = 2.0 * cc / (-b + sd)
+    else:
+        minus = (-b - sd) / (2.0 * a)
+        plus = 2.0 * cc / (-b - sd)
+    fast, slow = (plus, minus) if abs(plus) <= abs(minus) else (minus, plus)
+    return plus, minus, fast, slow
+
+
+def ray_init_XYZ_k_direction(p: RaysParams, rf: Dict[str, Any], rvec, nvec, tab=None):
+    """one_ray_init_XYZ_k_direction_m.f90:116-160: the refractive index vector of the requested mode along the
+    direction `nvec` at `rvec`; (None, err) when the equilibrium refuses the point.  The reference takes the REAL
+    square root of nsq (dispersion_solvers_m.f90:221), so an evanescent direction yields NaNs, not a dropped ray.
+    acos / cos are the host libm's, as in the reference."""
+    modes = {"plus": 0, "minus": 1, "fast": 2, "slow": 3}
+    wm = str(rf.get("wave_mode", "")).strip()
+    if wm not in modes:
+        raise ConfigError(f"solve_disp: improper wave_mode = {wm!r}")
+    err, bunit, alpha, gamma, _ = _launch_eq(p, np.asarray(rvec, dtype=np.float64), tab)
+    if err:
+        return None, err
+    n = np.asarray(nvec, dtype=np.float64)
+    n = n / math.sqrt((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2])
+    cos_theta = (bunit[0] * n[0] + bunit[1] * n[1]) + bunit[2] * n[2]
+    theta = math.acos(cos_theta)
+    nsq = solve_cold_nsq_vs_theta(alpha, gamma, theta)
+    if nsq is None:
+        raise ConfigError("disp_solve_cold_nsq_vs_theta: evanescent root (nsq undefined in the reference)")
+    v = nsq[modes[wm]]
+    n_re = float(int(rf.get("k0_sign", 1))) * (math.sqrt(v) if v >= 0.0 else float("nan"))
+    return n_re * n, 0
+
+
+def one_ray_init_XYZ_n_direction(p: RaysParams, nml: Dict[str, Dict[str, Any]], tab=None):
+    """one_ray_init_XYZ_k_direction_m.f90:28-114: one ray from /one_ray_init_XYZ_k_direction_list/."""
+    g = nml.get("one_ray_init_xyz_k_direction_list", {})
+    rvec = np.array([float(g.get(k, 0.0)) for k in ("x", "y", "z")])
+    nvec = np.array([float(g.get(k, 0.0)) for k in ("nx", "ny", "nz")])
+    if int(nml.get("ray_init_list", {}).get("nray_max", 1)) < 1:
+        raise ConfigError("one_ray_init_XYZ_n_direction: improper number of rays  nray= 1")
+    if not bool(g.get("use_this_n_vec", False)):
+        nvec, err = ray_init_XYZ_k_direction(p, nml.get("rf_list", {}), rvec, nvec, tab)
+        if err:
+            raise ConfigError("No successful ray initializations")
+    return rvec[None, :].copy(), np.asarray(nvec)[None, :].copy(), np.ones(1)
+
+
+def file_input_ray_init(p: RaysParams, nml: Dict[str, Dict[str, Any]], base_dir: str, tab=None):
+    """file_input_ray_init_m.f90:34-143: positions and directions from ray_init_<run_label>.in; rays the equilibrium
+    refuses are dropped.  (ray_pwr_wt: the reference scales a work array it never fills, :131 -- zeros -- unless
+    every ray_pwr_wt_in is zero, :128-129.)"""
+    import os
+
+    from .namelist import read_namelist
+
+    label = str(nml.get("diagnostics_list", {}).get("run_label", "")).strip()
+    nray_max = int(nml.get("ray_init_list", {}).get("nray_max", 1))
+    g = read_namelist(os.path.join(base_dir, f"ray_init_{label}.in")).get("file_input_ray_init_list", {})
+    n_in = int(g.get("n_rays_in", 0))
+    if n_in < 1 or n_in > nray_max:
+        raise ConfigError(f"file_input_ray_init: improper number of rays  n_rays_in= {n_in}")
+    r_in = np.array(_arr(g.get("rvec_in"), 3 * nray_max, 0.0), dtype=np.float64).reshape(nray_max, 3)
+    n_in_vec = np.array(_arr(g.get("rindex_vec_in"), 3 * nray_max, 0.0), dtype=np.float64).reshape(nray_max, 3)
+    w_in = np.array(_arr(g.get("ray_pwr_wt_in"), nray_max, 1.0), dtype=np.float64)
+    rv, nv = [], []
+    failed = False   # the reference's `init_err` is a saved variable that is never cleared (:33, :99-107): once a
+    for i in range(n_in):   # ray has been refused, every later ray of the file is dropped as well
+        n, err = ray_init_XYZ_k_direction(p, nml.get("rf_list", {}), r_in[i], n_in_vec[i], tab)
+        failed = failed or bool(err)
+        if failed:
+            continue
+        rv.append(r_in[i].copy())
+        nv.append(n)
+    if not rv:
+        raise ConfigError("No successful ray initializations")
+    nray = len(rv)
+    w = np.full(nray, 1.0 / nray) if w_in.max() == 0.0 else np.zeros(nray)
+    return np.ascontiguousarray(rv), np.ascontiguousarray(nv), w
+
+
+def initialize_ray_init(p: RaysParams, nml: Dict[str, Dict[str, Any]], axisym_tables=None, base_dir: str = "."):
+    """ray_init_m.f90:72-127 dispatch on ray_init_model (`base_dir`: where a file_input_ray_init run finds its
+    ray_init_<run_label>.in -- the run directory)."""
     model = str(nml.get("ray_init_list", {}).get("ray_init_model", "")).strip()
+    if model in ("one_ray_init_XYZ_n_direction", "file_input_ray_init"):
+        if p.equilib_model == EQUILIB["axisym_toroid"] and p.axisym.magnetics_model != 0:
+            raise ConfigError(f"{model}: the Python host mirror has no axisym_toroid fields for this magnetics_model")
+        if model == "file_input_ray_init":
+            return file_input_ray_init(p, nml, base_dir, axisym_tables)
+        return one_ray_init_XYZ_n_direction(p, nml, axisym_tables)
     if model == "simple_slab":
         return simple_slab_ray_init(p, nml)
     if model == "solovev":

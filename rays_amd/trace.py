@@ -104,7 +104,8 @@ class RaysRun:
             hip.set_axisym_tables(tab)
             if "rho_grid" in tab:
                 hip.set_rho_table(tab["rho_grid"], tab["rho_fspl"])
-        r0, n0, w = initialize_ray_init(p, nml, tab)
+        import os
+        r0, n0, w = initialize_ray_init(p, nml, tab, base_dir=os.path.dirname(os.path.abspath(path)))
         return cls(p, r0, n0, w, nml)
 
     @property

@@ -20,7 +20,16 @@ GOLDEN_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_n
                 "gold_solovev64_damp_multi_sg", "gold_slab16_damp_multi_grad_rk4",
                 "gold_axisym64_solmag_damp_rk4", "gold_axisym64_solmag_sg_num",
                 "gold_axisym64_solmag_splines_grad_rk4",
-                "gold_axisym64_eqlin_damp_rk4", "gold_axisym64_eqlin_tspline_sg_num"]
+                "gold_axisym64_eqlin_damp_rk4", "gold_axisym64_eqlin_tspline_sg_num",
+                "gold_slab_one_ray_rk4", "gold_solovev_file_rays_damp_rk4"]
+
+# launchers that take single rays by position and direction: host-side in every build (the reference's own routine under
+# the Fortran host, rays_amd/ray_init.py under the Python one); rays_hip_ray_init has no model for them
+HOST_ONLY_LAUNCHERS = ("one_ray_init_XYZ_n_direction", "file_input_ray_init")
+
+
+def launcher_model(nml):
+    return str(nml.get("ray_init_list", {}).get("ray_init_model", "")).strip()
 
 
 def load_golden(name):

@@ -80,6 +80,9 @@ CASES = [
     ("gold_axisym64_solmag_splines_grad_rk4", "gold_axisym64_solmag_splines_grad_rk4.in", list(range(0, 64, 9)), 25, 0),
     ("gold_axisym64_eqlin_damp_rk4", "gold_axisym64_eqlin_damp_rk4.in", list(range(0, 64, 5)), 10, 0),
     ("gold_axisym64_eqlin_tspline_sg_num", "gold_axisym64_eqlin_tspline_sg_num.in", list(range(0, 64, 7)), 0, 0),
+    # launchers that take single rays by position and direction (host-side in every build: acos / cos of libm)
+    ("gold_slab_one_ray_rk4", "gold_slab_one_ray_rk4.in", None, 0, 0),
+    ("gold_solovev_file_rays_damp_rk4", "gold_solovev_file_rays_damp_rk4.in", None, 0, 0),
 ]
 
 
@@ -121,7 +124,7 @@ def main():
         with tempfile.TemporaryDirectory() as d:
             shutil.copy(os.path.join(ROOT, "configs", cfg), os.path.join(d, "rays.in"))
             for f in os.listdir(os.path.join(ROOT, "configs")):
-                if f.endswith(".geqdsk"):
+                if f.endswith(".geqdsk") or f.startswith("ray_init_"):   # (file_input_ray_init reads ray_init_<run_label>.in)
                     shutil.copy(os.path.join(ROOT, "configs", f), d)
             env = dict(os.environ, RAYS_DUMP_FILE="dump.bin", RAYS_DUMP_PROBE=str(stride),
                        RAYS_DUMP_AXISYM="axisym.bin", RAYS_DUMP_DEPOSITION="dep.bin")

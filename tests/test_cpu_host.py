@@ -49,7 +49,7 @@ def test_ray_init_equals_reference(name):
         pytest.skip("'solovev_magnetics' / 'eqdsk_magnetics_lin_interp' have no Python host mirror: the fan comes from the device launcher "
                     "(test_cpu_kernel_emul.py::test_ray_init_source_on_host_equals_reference, test_gpu_parity.py)")
     tab = {k[4:]: (float(g[k]) if g[k].ndim == 0 else g[k]) for k in g.files if k.startswith("axi_")}
-    r0, n0, _ = initialize_ray_init(p, nml, tab or None)
+    r0, n0, _ = initialize_ray_init(p, nml, tab or None, base_dir=os.path.join(ROOT, "configs"))
     assert len(r0) == int(g["nray_full"])
     np.testing.assert_array_equal(r0, g["rvec0_full"])
     np.testing.assert_array_equal(n0, g["rindex_vec0_full"])

@@ -79,7 +79,10 @@ def test_ray_init_source_on_host_equals_reference(name):
     rays_ray_init.hpp compiled for the host reproduce the reference launcher's fan bit for bit
     (rvec0, rindex_vec0 and the ray numbering after evanescent launches are dropped)."""
     from rays_amd.ray_init import fan_from_namelist
+    from tests.common import HOST_ONLY_LAUNCHERS, launcher_model
     g, nml, p = load_golden(name)
+    if launcher_model(nml) in HOST_ONLY_LAUNCHERS:
+        pytest.skip("host-side launcher (no rays_hip_ray_init model)")
     fan, nray_max = fan_from_namelist(nml)
     r0, n0 = emul_lib.ray_init(p, fan, nray_max)
     np.testing.assert_array_equal(r0, g["rvec0_full"])

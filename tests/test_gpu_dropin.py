@@ -25,7 +25,7 @@ def _run(binary, cfg, d, extra_env=None):
     os.makedirs(d, exist_ok=True)
     shutil.copy(os.path.join(ROOT, "configs", cfg), os.path.join(d, "rays.in"))
     for f in os.listdir(os.path.join(ROOT, "configs")):
-        if f.endswith(".geqdsk"):
+        if f.endswith(".geqdsk") or f.startswith("ray_init_"):   # (file_input_ray_init reads ray_init_<run_label>.in)
             shutil.copy(os.path.join(ROOT, "configs", f), d)
     env = dict(os.environ, RAYS_DUMP_FILE="dump.bin", RAYS_DUMP_PROBE="0", **(extra_env or {}))
     subprocess.run([binary], cwd=d, env=env, check=True, stdout=subprocess.DEVNULL, timeout=600)
@@ -40,7 +40,8 @@ def _run(binary, cfg, d, extra_env=None):
                                  "gold_solovev64_damp_rk4.in", "gold_axisym64_eqdsk_damp_rk4.in",
                                  "gold_slab_lin2_rk4_num.in", "gold_slab_negative_dens_rk4.in",
                                  "gold_solovev64_slow_sg.in", "gold_axisym64_solmag_damp_rk4.in",
-                                 "gold_axisym64_solmag_splines_grad_rk4.in", "gold_axisym64_eqlin_damp_rk4.in"])
+                                 "gold_axisym64_solmag_splines_grad_rk4.in", "gold_axisym64_eqlin_damp_rk4.in",
+                                 "gold_slab_one_ray_rk4.in", "gold_solovev_file_rays_damp_rk4.in"])
 def test_fortran_dropin_equals_reference_binary(cfg):
     with tempfile.TemporaryDirectory() as d:
         ref = _run(REF, cfg, os.path.join(d, "ref"))
