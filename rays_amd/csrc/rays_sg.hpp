@@ -75,15 +75,16 @@ enum : int {
 // the first version of this kernel spent ~100 us per trip there against ~3 us in the RHS.
 //
 // SG_ode restarts the integrator on every output interval (SG_ode_m.f90:118-122), so the order
-// stays low: k <= 4 in 99.5 % and k <= 6 in 99.97 % of the steps of the Solovev fans.  Storage is
-// therefore tiered by index:
+// stays low: k <= 4 in 99.7 % of the step attempts of the Solovev fan with finite-difference dD (cfg 3), k <= 4 in
+// 84 % and k <= 6 in 96.7 % on the eqdsk fan with damping (cfg 5; counted with the C restatement).
+// Storage is therefore tiered by index:
 //   coefficient entries 1..6          LDS, lane-interleaved (element e of lane L at col[e * 64])
 //   phi rows 1..2                     registers: every loop over rows is unrolled over q with the lane's
 //                                     bounds as predicates and a wave-uniform skip
 //   phi rows 3..2+LR (LR = 44/nv)     LDS
 //   everything above, the round-off   the launch's global workspace (TraceArgs::sg_far, [slot][lane], so a wave's
-//   rows 15-16 and y of SG_ode        access coalesces); reached in < 1 % of the steps, except rows 15-16, which
-//                                     are read and written once per step
+//   rows 15-16 and y of SG_ode        access coalesces); reached in < 1 % of the steps on the Solovev fans and in
+//                                     ~9 % on the eqdsk fan, except rows 15-16, which are read and written once per step
 // No private arrays: a dynamically indexed private array is scratch memory, and with it came 0.9-1.1 KB of
 // scratch per lane, 115-180 SGPR spills and an HBM write stream 12x the trajectory's (round 1).  Now the kernels
 // have 0-100 B of scratch per lane.  LDS per lane: 36 + LR x nv <= 80 doubles = the CU's 160 KB for its four waves,
