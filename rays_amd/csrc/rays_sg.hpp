@@ -99,9 +99,10 @@ enum : int {
 // workspace: tier 5 -> 112.6 | 336.2, tier 6 -> 111.0 | 318.6, tier 8 -> 114.3 | 342.8; round-off rows in LDS instead
 // (fewer phi rows fit): tier 5 -> 118.3 | 333.5, tier 7 -> 135.6 | 343.9.  What decides is how many phi rows fit.
 #endif
-#ifndef RAYS_SG_REG_ROWS
-#define RAYS_SG_REG_ROWS 2  // measured on the 256k-ray eqdsk fan: 2 | 4 | 6 | 8 register rows -> 119 | 125 | 168 | 320 ms
-#endif
+// phi rows in registers: 2, and 3 for nv = 8 (the eqdsk + damping fans reach order 6 in 5 % of their step attempts;
+// the third register row moves the LDS rows up to 4..8, so that order stays out of the workspace).  Measured with the
+// final control flow (cfg 5 nv = 8 | cfg 3 nv = 7, ms, one box): 2 rows 97.1-97.5 | 301-304, 3 rows 95.0 | 308.5,
+// 4 rows 95.3-95.5 | 309-320, 6 rows 104-105 | 319.5.
 constexpr int kSgTier = RAYS_SG_TIER;  // coefficient entries held in LDS
 // LDS pointers carry their address space explicitly: the tiered accessors choose between an LDS
 // and a private location, and with generic pointers LLVM may merge the two loads into one load
@@ -120,7 +121,14 @@ constexpr int sg_phi_lds_rows() {
   return (80 - 6 * kSgTier) / NV < 1 ? 1 : (80 - 6 * kSgTier) / NV;
 #endif
 }
-constexpr int kSgPhiRegRows = RAYS_SG_REG_ROWS;
+template <int NV>
+constexpr int sg_phi_reg_rows() {
+#ifdef RAYS_SG_REG_ROWS
+  return RAYS_SG_REG_ROWS;
+#else
+  return NV == 8 ? 3 : 2;
+#endif
+}
 
 // This lane's column of the launch's upper-tier workspace (TraceArgs::sg_far, element e at column[e * stride]).
 // Recomputed where it is needed (rare) from the kernel arguments instead of being carried in registers.
@@ -372,7 +380,7 @@ struct SgPhi {
 // doubles per lane of the launch's global workspace (TraceArgs::sg_far): the tiers above LDS
 template <int NV>
 constexpr int sg_far_doubles_per_lane() {
-  return SgCoef::kFarDoubles + SgPhi<NV, kSgPhiRegRows, sg_phi_lds_rows<NV>()>::kFarDoubles + 2 * NV + NV;  // + round-off rows 15, 16 + y (below)
+  return SgCoef::kFarDoubles + SgPhi<NV, sg_phi_reg_rows<NV>(), sg_phi_lds_rows<NV>()>::kFarDoubles + 2 * NV + NV;  // + round-off rows 15, 16 + y (below)
 }
 // y of SG_ode -- the ray state the reference's `ode` was last entered with or returned (the last completed output
 // point, or the state after a tolerance-inflation restart).  It is only READ when a ray stops (end_ray_vec), so
@@ -418,7 +426,7 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
-  constexpr int RR = kSgPhiRegRows, LR = sg_phi_lds_rows<NV>();
+  constexpr int RR = sg_phi_reg_rows<NV>(), LR = sg_phi_lds_rows<NV>();
   const sg_lds_ptr lane_lds = (sg_lds_ptr)(lds + wave * SgLds<NV>::kDoublesPerWave + lane);
   SgCoef S;
   S.col = lane_lds;
