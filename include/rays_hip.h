@@ -227,6 +227,20 @@ int rays_hip_set_axisym_tables(const rays_axisym_tables_t* t);
  * what would leave the array altogether (undefined in the reference). */
 int rays_hip_set_eqdsk_lin_tables(const rays_axisym_tables_t* t, double dR, double dZ);
 
+/* Numerics of the trace kernels (process-wide; read when a trace is launched).
+ *   RAYS_NUMERICS_EXACT (default): IEEE binary64 in the reference's operation order, no FMA contraction,
+ *     correctly rounded quotients and roots -- trajectories bit-identical to the reference CPU path.
+ *   RAYS_NUMERICS_TOLERANCE: the bar BASELINE.json's north_star states -- every step within 1e-10 relative of the
+ *     reference's, ray counts / step indices / stop flags exactly the reference's -- which lets the kernels fuse
+ *     a*b+c and use once-refined reciprocals and roots.  Built for ode_solver = RK4 with ray_deriv = cold (without
+ *     multi_spec_damping); every other configuration runs its exact kernel under either setting (finite-difference
+ *     dD amplifies an ulp by 1e8, and the adaptive solver then takes another step sequence).
+ * The environment variable RAYS_HIP_NUMERICS = exact | tolerance sets the initial value.  Returns the previous
+ * setting, or -1 for an unknown mode. */
+enum { RAYS_NUMERICS_EXACT = 0, RAYS_NUMERICS_TOLERANCE = 1 };
+int rays_hip_set_numerics(int mode);
+int rays_hip_get_numerics(void);
+
 /* Validates a parameter block exactly as the reference's `stop 1` configuration checks would;
  * 0 if the device path supports it. */
 int rays_hip_check_params(const rays_params_t* p);

@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -41,6 +42,12 @@ RAYS_DECL_ENTRIES(1, 1, 0)
 RAYS_DECL_ENTRIES(1, 1, 1)
 RAYS_DECL_ENTRIES(1, 2, 0)
 RAYS_DECL_ENTRIES(1, 2, 1)
+#define RAYS_DECL_TOL(e) \
+  const KernelEntry* rays_entries_tol_0_##e##_0_0_0(int* n); \
+  const KernelEntry* rays_entries_tol_0_##e##_0_1_0(int* n);
+RAYS_DECL_TOL(0)
+RAYS_DECL_TOL(1)
+RAYS_DECL_TOL(2)
 hipError_t launch_pack(bool pack, int nray, int nv, int nstep_max, const int32_t* npoints,
                        const long long* offsets, double* ray_vec, double* residual, double* packed_vec,
                        double* packed_res, hipStream_t stream);
@@ -112,6 +119,13 @@ const FlagText kFlags[] = {
 static_assert(rays::kBlock == rays::PointWindow<7>::kStride, "PointWindow rows are laid out for the launch block size");
 #include "rays_dev_params.inc"
 
+// rays_hip_set_numerics: RAYS_NUMERICS_* (include/rays_hip.h)
+int initial_numerics() {
+  const char* e = std::getenv("RAYS_HIP_NUMERICS");
+  return e && (e[0] == 't' || e[0] == 'T' || e[0] == '1') ? RAYS_NUMERICS_TOLERANCE : RAYS_NUMERICS_EXACT;
+}
+std::atomic<int> g_numerics{initial_numerics()};
+
 // nray: fan size (0 = unknown).  From two waves per SIMD worth of rays on, the two-waves-per-SIMD build
 // of the kernel is preferred where one exists (rays_rk4.hpp).
 const rays::KernelEntry* find_kernel(const rays_params_t& p, long long nray = 0) {
@@ -124,9 +138,16 @@ const rays::KernelEntry* find_kernel(const rays_params_t& p, long long nray = 0)
       {{RAYS_G(0, 0, 0), RAYS_G(0, 0, 1)}, {RAYS_G(0, 1, 0), RAYS_G(0, 1, 1)}, {RAYS_G(0, 2, 0), RAYS_G(0, 2, 1)}},
       {{RAYS_G(1, 0, 0), RAYS_G(1, 0, 1)}, {RAYS_G(1, 1, 0), RAYS_G(1, 1, 1)}, {RAYS_G(1, 2, 0), RAYS_G(1, 2, 1)}}};
 #undef RAYS_G
+  // tolerance flavour of the cold RK4 groups [equilibrium][unit exponents]
+  static const Getter tol_getters[3][2] = {{rays_entries_tol_0_0_0_0_0, rays_entries_tol_0_0_0_1_0},
+                                           {rays_entries_tol_0_1_0_0_0, rays_entries_tol_0_1_0_1_0},
+                                           {rays_entries_tol_0_2_0_0_0, rays_entries_tol_0_2_0_1_0}};
   int n = 0;
-  const KernelEntry* e = getters[p.ode_solver][p.equilib_model][p.ray_deriv][unit_exponents(p) ? 1 : 0]
-                                [p.multi_spec_damping ? 1 : 0](&n);
+  const bool tol = g_numerics.load() == RAYS_NUMERICS_TOLERANCE && p.ode_solver == RAYS_ODE_RK4 &&
+                   p.ray_deriv == RAYS_DERIV_COLD && !p.multi_spec_damping;
+  const KernelEntry* e = tol ? tol_getters[p.equilib_model][unit_exponents(p) ? 1 : 0](&n)
+                             : getters[p.ode_solver][p.equilib_model][p.ray_deriv][unit_exponents(p) ? 1 : 0]
+                                      [p.multi_spec_damping ? 1 : 0](&n);
   int ncu = 256;
   {
     int dev = 0;
@@ -374,6 +395,15 @@ int set_axisym_tables_impl(const rays_axisym_tables_t* t, bool lin, double dR, d
 }  // namespace
 
 int rays_hip_sizeof_params(void) { return (int)sizeof(rays_params_t); }
+
+int rays_hip_set_numerics(int mode) {
+  if (mode != RAYS_NUMERICS_EXACT && mode != RAYS_NUMERICS_TOLERANCE) {
+    g_err = "rays_hip_set_numerics: unknown mode";
+    return -1;
+  }
+  return g_numerics.exchange(mode);
+}
+int rays_hip_get_numerics(void) { return g_numerics.load(); }
 
 int rays_hip_device_count(void) {
   int n = 0;
@@ -752,6 +782,24 @@ static void cached_free(int slot, void* ptr) {
   c.live.erase(it);
 }
 
+// A cache slot serves one device at a time (its stream and idle blocks live there).  Every user of a slot -- the
+// blocks of rays_hip_trace and of rays_hip_trace_gather alike -- claims it for the device it is about to use: a slot
+// that last served another device (e.g. four slots on device 0 for a large fan, then one slot per device for a
+// gather) first gives that device's blocks and stream back.  Caller has `dev` current; it is current on return.
+static void claim_slot_for_device(int slot, int dev) {
+  if (slot < 0 || slot >= 17) return;
+  DeviceBlockCache& c = g_blocks[slot];
+  std::lock_guard<std::mutex> lk(c.mu);
+  if (c.device >= 0 && c.device != dev) {
+    (void)hipSetDevice(c.device);
+    c.drop_idle();
+    if (c.stream) (void)hipStreamDestroy(c.stream);
+    c.stream = nullptr;
+    (void)hipSetDevice(dev);
+  }
+  c.device = dev;
+}
+
 static void release_cached_device_blocks() {
   for (int d = 0; d < 17; d++) {
     DeviceBlockCache& c = g_blocks[d];
@@ -828,18 +876,7 @@ static int trace_block_on_device(int slot, int dev, const rays_params_t* p, int 
     t_prev = now;
   };
   DEV_TRY(hipSetDevice(dev));
-  if (slot >= 0 && slot < 16) {  // a slot that moved to another device gives its cached buffers back first
-    DeviceBlockCache& c = g_blocks[slot];
-    std::lock_guard<std::mutex> lk(c.mu);
-    if (c.device >= 0 && c.device != dev) {
-      (void)hipSetDevice(c.device);
-      c.drop_idle();
-      if (c.stream) (void)hipStreamDestroy(c.stream);
-      c.stream = nullptr;
-      (void)hipSetDevice(dev);
-    }
-    c.device = dev;
-  }
+  claim_slot_for_device(slot, dev);
   hipStream_t st;
   bool own_stream = false;
   DEV_TRY(cached_stream(slot, &st, &own_stream));

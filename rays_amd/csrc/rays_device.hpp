@@ -150,6 +150,9 @@ constexpr int kEqUnitExp = 4;
 // Carried in EQ as well, because nv alone is ambiguous (nv = 12 is integrate_eq_gradients without damping, or
 // damping + four species' rows; nv = 13 likewise).
 constexpr int kEqMultiSpec = 8;
+// Tolerance flavour of a kernel (see fdiv / fsqrt below): same source, compiled in its own translation unit
+// with -DRAYS_TOL_FLAVOUR -ffp-contract=fast; the bit only gives the kernel another name.
+constexpr int kEqTol = 16;
 // Layout of the ODE vector (ode_m.f90:160-173, initialize_ode_vector.f90:25-54):
 //   v(1:6) = (r, k), v(7) = s, [v(8) = total absorbed power, [v(9:9+nspec) per species]], [5 gradient rows]
 template <bool MULTI, int NS, int NV>
@@ -190,6 +193,37 @@ struct Recip {
 RAYS_DEV Recip make_recip(double d) { return Recip{d, 0.}; }
 RAYS_DEV Recip const_recip(double d, double) { return Recip{d, 0.}; }
 RAYS_DEV double div(double a, const Recip& R) { return a / R.d; }
+RAYS_DEV double fdiv(double a, double b) { return a / b; }
+RAYS_DEV double fsqrt(double x) { return sqrt(x); }
+#elif defined(RAYS_TOL_FLAVOUR)
+// ---- tolerance flavour (kEqTol kernels; this translation unit is compiled with -ffp-contract=fast) ----------
+// north_star's bar for floating point is 1e-10 relative per step with exact ray counts and step indices, not
+// bit-identity.  The cold RK4 kernels exist a second time with that bar: quotients are a * (1/d) with the
+// reciprocal refined once (v_rcp_f64 + one Newton step: ~1 ulp) instead of the correctly rounded RN(a/d)
+// (mul + 2 FMA + v_div_fixup per quotient), square roots are v_rsq_f64 + one coupled Newton step + one residual
+// correction (~1 ulp) instead of LLVM's correctly rounded expansion, and the compiler may fuse a*b+c.
+// v_div_fixup on the reciprocal keeps 1/0 = inf, 1/inf = 0 and NaN as IEEE has them, so the NaN / inf polarity
+// of the comparisons that stop a ray is unchanged.
+RAYS_DEV Recip make_recip(double d) {
+  double y = __builtin_amdgcn_rcp(d);
+  const double e = __builtin_fma(-d, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  return Recip{d, __builtin_amdgcn_div_fixup(y, d, 1.0)};
+}
+RAYS_DEV Recip const_recip(double d, double inv) { return Recip{d, inv}; }
+RAYS_DEV double div(double a, const Recip& R) { return a * R.rc; }
+RAYS_DEV double fdiv(double a, double b) { return a * make_recip(b).rc; }
+RAYS_DEV double fsqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  const double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  // +-0 and +inf: rsq gives inf / 0 and the products above NaN; sqrt returns the argument itself
+  return __builtin_amdgcn_class(x, 0x260) ? x : g;  // 0x260 = -0 | +0 | +inf
+}
 #else
 RAYS_DEV Recip make_recip(double d) {
   double y = __builtin_amdgcn_rcp(d);
@@ -206,11 +240,17 @@ RAYS_DEV double div(double a, const Recip& R) {
   const double q1 = __builtin_fma(r, R.rc, q);
   return __builtin_amdgcn_div_fixup(q1, R.d, a);
 }
+// a / b and sqrt as IEEE has them (the tolerance flavour above replaces both)
+RAYS_DEV double fdiv(double a, double b) { return a / b; }
+RAYS_DEV double fsqrt(double x) { return sqrt(x); }
 #endif
 
 // compiler-rt __divdc3 restricted to (a + 0i)/(c + 0i) -> real part; what flang emits for
 // real/complex and complex/real quotients (check_save.f90:226, suscep_m.f90:75).
 RAYS_DEV double divdc3_real(double a, double c) {
+#if defined(RAYS_TOL_FLAVOUR) && !defined(RAYS_HOST_EMUL)
+  return fdiv(a, c);
+#endif
   double fc = fabs(c);
   int k = 0;
   // logb(|c|) finite <=> c finite and non-zero
@@ -280,19 +320,19 @@ RAYS_DEV int slab_fields(const DevParams& P, const double rvec[3], double bvec[3
   if (P.by_model == RAYS_SLAB_BY_CONSTANT) {  // :184-206
     bvec[1] = P.by0;
   } else if (P.by_model == RAYS_SLAB_BY_TOROID) {
-    bvec[1] = P.by0 / (1. + x / P.s_rmaj);
-    gbt[0][1] = -bvec[1] / (P.s_rmaj + x);
+    bvec[1] = fdiv(P.by0, 1. + fdiv(x, P.s_rmaj));
+    gbt[0][1] = fdiv(-bvec[1], P.s_rmaj + x);
   } else if (P.by_model == RAYS_SLAB_BY_LINEAR_SHEAR) {
-    bvec[1] = P.by0 * x / P.LBy;
+    bvec[1] = fdiv(P.by0 * x, P.LBy);
     gbt[0][1] = P.by0_over_LBy;
   }
   if (P.bz_model == RAYS_SLAB_BZ_CONSTANT) {  // :209-233
     bvec[2] = P.bz0;
   } else if (P.bz_model == RAYS_SLAB_BZ_TOROID) {
-    bvec[2] = P.bz0 / (1. + x / P.s_rmaj);
-    gbt[0][2] = -bvec[2] / (P.s_rmaj + x);
+    bvec[2] = fdiv(P.bz0, 1. + fdiv(x, P.s_rmaj));
+    gbt[0][2] = fdiv(-bvec[2], P.s_rmaj + x);
   } else if (P.bz_model == RAYS_SLAB_BZ_LINEAR) {
-    bvec[2] = P.bz0 * (1. + x / P.LBz);
+    bvec[2] = P.bz0 * (1. + fdiv(x, P.LBz));
     gbt[0][2] = P.bz0_over_LBz;
   } else {
     bvec[2] = P.bz0 + P.dBzdx * (x - P.x0);
@@ -302,7 +342,7 @@ RAYS_DEV int slab_fields(const DevParams& P, const double rvec[3], double bvec[3
 #pragma unroll
     for (int is = 0; is < NS; is++) ns[is] = P.n0s[is];
   } else if (P.n_model == RAYS_SLAB_N_LINEAR) {
-    const double f = 1.0 + x / P.Ln;
+    const double f = 1.0 + fdiv(x, P.Ln);
 #pragma unroll
     for (int is = 0; is < NS; is++) {
       ns[is] = P.n0s[is] * f;
@@ -323,8 +363,8 @@ RAYS_DEV int slab_fields(const DevParams& P, const double rvec[3], double bvec[3
       gradns[is][0] = P.n0s[is] * fp;
     }
   } else {  // Gaussian
-    const double g = libm::exp(-3. * P.s_an1 * sq(x / P.s_rmin));
-    const double gp = -6. * P.s_an1 * x / P.rmin2;
+    const double g = libm::exp(-3. * P.s_an1 * sq(fdiv(x, P.s_rmin)));
+    const double gp = fdiv(-6. * P.s_an1 * x, P.rmin2);
 #pragma unroll
     for (int is = 0; is < NS; is++) {
       ns[is] = P.n0s[is] * g;
@@ -337,7 +377,7 @@ RAYS_DEV int slab_fields(const DevParams& P, const double rvec[3], double bvec[3
     if (m == RAYS_SLAB_T_CONSTANT) {
       ts[is] = P.t0s[is];
     } else if (m == RAYS_SLAB_T_LINEAR) {
-      ts[is] = P.t0s[is] * (1. + x / P.LT);
+      ts[is] = P.t0s[is] * (1. + fdiv(x, P.LT));
       gradts[is][0] = P.t0s[is] * P.one_over_LT;
     } else if (m == RAYS_SLAB_T_LINEAR_2) {
       ts[is] = P.t0s[is] + P.dtdx * (x - P.x0);
@@ -411,7 +451,7 @@ RAYS_DEV int solovev_fields(const DevParams& P, const double rvec[3], double bve
                             double gradts[NS][3], bool check_box) {
   int err = 0;
   const double x = rvec[0], y = rvec[1], z = rvec[2];
-  const double r = sqrt(x * x + y * y);
+  const double r = fsqrt(x * x + y * y);
   if (r < P.box_rmin || r > P.box_rmax) err = RAYS_STOP_R_OUT_OF_BOX;  // :155
   if (z < P.box_zmin || z > P.box_zmax) err = RAYS_STOP_Z_OUT_OF_BOX;  // :156
   if (!check_box) err = 0;
@@ -496,7 +536,7 @@ RAYS_DEV int spl_cell(PTR x, int nx, double xget, double& dx) {
   if (z < x1) z = x1;
   if (z > xn) z = xn;
   const int nxm = nx - 1;
-  int i = (int)(1 + nxm * (z - x1) / (xn - x1));
+  int i = (int)(1 + fdiv(nxm * (z - x1), xn - x1));
   i = i < nxm ? i : nxm;
   i = i < 1 ? 1 : i;
   if (z < x[i - 1]) i = i - 1;
@@ -662,7 +702,7 @@ RAYS_DEV int axisym_fields(const DevParams& P, const double rvec[3], double bvec
   constexpr double Tiny = 10.0e-14;
   int err = 0;
   const double x = rvec[0], y = rvec[1], z = rvec[2];
-  const double r = sqrt(x * x + y * y);
+  const double r = fsqrt(x * x + y * y);
   if (r < P.a_box_rmin - Tiny || r > P.a_box_rmax + Tiny) err = RAYS_STOP_AXI_R_OUT_OF_BOX;  // :261-264
   if (z < P.a_box_zmin - Tiny || z > P.a_box_zmax + Tiny) err = RAYS_STOP_AXI_Z_OUT_OF_BOX;  // :265-268
   bool boxed = check_box && err != 0;  // reference returns here; fields below are then unused
@@ -813,7 +853,7 @@ RAYS_DEV void equilibrium(const DevParams& P, const Recip& Romgrf, const Recip& 
   // When err != 0 the reference returns with eq undefined (:198-202).  We still fill it (fields
   // evaluated at the out-of-box point): callers that stop on err never read it, and check_save,
   // which does read it, then sees defined data (DESIGN.md "defined where the reference is not").
-  const double bmag = sqrt(sq(eq.bvec[0]) + sq(eq.bvec[1]) + sq(eq.bvec[2]));  // :238
+  const double bmag = fsqrt(sq(eq.bvec[0]) + sq(eq.bvec[1]) + sq(eq.bvec[2]));  // :238
   eq.bmag = bmag;
   const Recip Rb = make_recip(bmag);
   eq.rbmag = Rb;
@@ -858,7 +898,7 @@ RAYS_DEV void deriv_cold(const DevParams& P, const EqPoint<NS>& eq, const double
   double np[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) np[i] = nvec[i] - n3 * eq.bunit[i];
-  const double n1 = sqrt(sq(np[0]) + sq(np[1]) + sq(np[2]));  // :46
+  const double n1 = fsqrt(sq(np[0]) + sq(np[1]) + sq(np[2]));  // :46
   double dn3dk[3], dn12dk[3], dn3dx[3], dn12dx[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
@@ -985,7 +1025,7 @@ RAYS_DEV void eps_cold(const double alpha[NS], const double gamma[NS], double& e
 #pragma unroll
   for (int is = 0; is < NS; is++) {
     const double omg2 = 1. - sq(gamma[is]);
-    s11 = s11 + (-alpha[is] / omg2);                           // suscep_m.f90:72
+    s11 = s11 + fdiv(-alpha[is], omg2);                         // suscep_m.f90:72
     s33 = s33 + (-alpha[is]);                                  // :74
     s12 = s12 + (-divdc3_real(alpha[is] * gamma[is], omg2));   // :75
   }
@@ -1009,7 +1049,7 @@ template <int NS>
 RAYS_DEV double determ(const double bunit[3], const double alpha[NS], const double gamma[NS],
                        const double kvec[3], const Recip& Rk0) {
   const double k3 = kvec[0] * bunit[0] + kvec[1] * bunit[1] + kvec[2] * bunit[2];
-  const double k1 = sqrt(sq(kvec[0] - k3 * bunit[0]) + sq(kvec[1] - k3 * bunit[1]) + sq(kvec[2] - k3 * bunit[2]));
+  const double k1 = fsqrt(sq(kvec[0] - k3 * bunit[0]) + sq(kvec[1] - k3 * bunit[1]) + sq(kvec[2] - k3 * bunit[2]));
   const double n1 = div(k1, Rk0), n3 = div(k3, Rk0);
   const double nsq = sq(n1) + 0. + sq(n3);
   double e11, e33, x12;
@@ -1114,6 +1154,12 @@ struct Cplx {
 };
 RAYS_DEV Cplx divdc3(Cplx x, Cplx y) {  // compiler-rt __divdc3, finite operands
   double c = y.re, d = y.im;
+#if defined(RAYS_TOL_FLAVOUR) && !defined(RAYS_HOST_EMUL)
+  {  // tolerance flavour: the textbook quotient without the logb scaling (operands are O(1) here)
+    const Recip Rd = make_recip(c * c + d * d);
+    return Cplx{div(x.re * c + x.im * d, Rd), div(x.im * c - x.re * d, Rd)};
+  }
+#endif
   const double m = fmax(fabs(c), fabs(d));
   int k = 0;
   if (m > 0.0 && m < __builtin_inf()) {
@@ -1128,23 +1174,25 @@ RAYS_DEV Cplx divdc3(Cplx x, Cplx y) {  // compiler-rt __divdc3, finite operands
   return r;
 }
 
-RAYS_DEV double zf_x(const DevParams& P, int i) {  // x_grid(i), 1-based (zfunctions_m.f90:444)
-  return P.zf_xmin + (double)(i - 1) * (P.zf_xmax - P.zf_xmin) / (double)(P.zf_nx - 1);
+// x_grid(i), 1-based (zfunctions_m.f90:444); Rn = shared reciprocal of nx - 1 (six quotients per lookup)
+RAYS_DEV double zf_x(const DevParams& P, int i, const Recip& Rn) {
+  return P.zf_xmin + div((double)(i - 1) * (P.zf_xmax - P.zf_xmin), Rn);
 }
 
 RAYS_DEV Cplx zfun_real_arg_spline(const DevParams& P, double z) {
   double re;
   if (fabs(z) <= 10.0) {  // spline_range
     const int nxm = P.zf_nx - 1;
-    const double x1 = zf_x(P, 1), xn = zf_x(P, P.zf_nx);
-    const double t = 1 + nxm * (z - x1) / (xn - x1);
+    const Recip Rn = make_recip((double)nxm);
+    const double x1 = zf_x(P, 1, Rn), xn = zf_x(P, P.zf_nx, Rn);
+    const double t = 1 + fdiv(nxm * (z - x1), xn - x1);
     int i = (int)t;  // NaN -> 0 on the device (undefined in Fortran); clamped below
     i = i < nxm ? i : nxm;
     i = i > 1 ? i : 1;
-    if (z < zf_x(P, i)) i = i - 1;
-    else if (z > zf_x(P, i + 1)) i = i + 1;
+    if (z < zf_x(P, i, Rn)) i = i - 1;
+    else if (z > zf_x(P, i + 1, Rn)) i = i + 1;
     i = i < 1 ? 1 : (i > nxm ? nxm : i);
-    const double dx = z - zf_x(P, i);
+    const double dx = z - zf_x(P, i, Rn);
     double f0, f1, f2, f3;
 #ifndef RAYS_HOST_EMUL
     if (P.zf_lds) {  // wave-uniform
@@ -1176,15 +1224,15 @@ RAYS_DEV double damp_fund_ech(const DevParams& P, const EqPoint<NS>& eq, const d
   const Recip Rk0 = const_recip(P.k0, P.inv_k0);
   const double nvec[3] = {div(kvec[0], Rk0), div(kvec[1], Rk0), div(kvec[2], Rk0)};
   const double k3 = kvec[0] * eq.bunit[0] + kvec[1] * eq.bunit[1] + kvec[2] * eq.bunit[2];
-  const double k1 = sqrt(sq(kvec[0] - k3 * eq.bunit[0]) + sq(kvec[1] - k3 * eq.bunit[1]) +
+  const double k1 = fsqrt(sq(kvec[0] - k3 * eq.bunit[0]) + sq(kvec[1] - k3 * eq.bunit[1]) +
                          sq(kvec[2] - k3 * eq.bunit[2]));
   const double R3 = div(k3, Rk0), R1 = div(k1, Rk0);
   const double R1S = sq(R1), R3S = sq(R3), RS = R1S + R3S;
   const double B1 = eq.gamma[0], BETAE = sq(B1);
   if (R3 == 0.) return 0.;  // :59
-  const double vth = sqrt(2. * eq.ts0 / P.ms[0]);
-  const double VT = vth / P.clight;
-  const double xi = (P.omgrf + eq.omgc0) / (k3 * vth);
+  const double vth = fsqrt(fdiv(2. * eq.ts0, P.ms[0]));
+  const double VT = fdiv(vth, P.clight);
+  const double xi = fdiv(P.omgrf + eq.omgc0, k3 * vth);
   if (fabs(xi) > 5.) return 0.;  // :73
   // zfun0_real_arg (:351-372).  The reference `stop 1`s the whole program when kz is neither
   // > 0 nor < 0, i.e. when the state is already NaN (a ray that left a parabolic-density plasma);
@@ -1198,13 +1246,13 @@ RAYS_DEV double damp_fund_ech(const DevParams& P, const EqPoint<NS>& eq, const d
     zf.im = -zf.im;
   }
   const double Pa = eq.alpha[0];
-  const double Q = Pa / 2. / (1 - B1);
+  const double Q = fdiv(Pa / 2., 1 - B1);
   const double L1 = (1. - Q) * RS * R1S + (1. - Pa) * RS * R3S - (1. - Q) * (1. - Pa) * (RS + R3S) -
                     (1 - 2. * Q) * R1S + (1 - 2 * Q) * (1 - Pa);
-  const double L2 = -(Pa / B1 * (RS * R1S - (1. - 2. * Q) * R1S)) +
-                    Pa * Pa / 4. / BETAE * R1S / R3S * (RS + R3S - 2. * (1. - 2. * Q));
+  const double L2 = -(fdiv(Pa, B1) * (RS * R1S - (1. - 2. * Q) * R1S)) +
+                    fdiv(fdiv(Pa * Pa / 4., BETAE) * R1S, R3S) * (RS + R3S - 2. * (1. - 2. * Q));
   const double L5 = Pa * (RS * R3S - (1. - Q) * (RS + R3S) + (1. - 2. * Q));
-  const double F = (1. - B1) * R3 * VT * (L1 + L2 + R1S / 2. / R3 / BETAE * VT * xi * L5);
+  const double F = (1. - B1) * R3 * VT * (L1 + L2 + fdiv(fdiv(R1S / 2., R3), BETAE) * VT * xi * L5);
   const Cplx one = {1., 0.};
   const Cplx zinv = divdc3(one, zf);
   const double par_re = xi + zinv.re, par_im = 0. + zinv.im;
@@ -1215,12 +1263,12 @@ RAYS_DEV double damp_fund_ech(const DevParams& P, const EqPoint<NS>& eq, const d
   const double B = -((1. - Pa) * A + sq(1. - Pa) - BETAE) + (A + (1. - Pa) * (1. - BETAE)) * R3S;
   const double DDNX2 = 2. * A * R1S + B;
   const double DDNZ = 2. * R3 * ((A + (1. - Pa) * (1. - BETAE)) * R1S + (1 - Pa) * (2. * (1. - BETAE) * R3S - 2. * A));
-  const double nvg = sqrt(sq(vg[0]) + sq(vg[1]) + sq(vg[2]));
+  const double nvg = fsqrt(sq(vg[0]) + sq(vg[1]) + sq(vg[2]));
   double dot = 0.;
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     const double ddn = DDNX2 * (2 * (nvec[i] - R3 * eq.bunit[i])) + DDNZ * eq.bunit[i];
-    dot += ddn * (vg[i] / nvg);
+    dot += ddn * fdiv(vg[i], nvg);
   }
   const Cplx num = {-(double)dw_re, -(double)dw_im};
   const Cplx den = {dot, 0.};
@@ -1240,12 +1288,12 @@ RAYS_DEV int ray_equations(const DevParams& P, const EqPoint<NS>& eq, const doub
   double vg[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) vg[i] = div(-dddk[i], Rw);
-  const double vg0 = sqrt(sq(vg[0]) + sq(vg[1]) + sq(vg[2]));
+  const double vg0 = fsqrt(sq(vg[0]) + sq(vg[1]) + sq(vg[2]));
   double dsd;
   if (P.ray_param == RAYS_PARAM_ARCL) {  // :150-170
     if (dddk[0] != 0. || dddk[1] != 0. || dddk[2] != 0.) {
       const double sgn = copysign(1.0, dddw);
-      const Recip Rnk = make_recip(sqrt(sq(dddk[0]) + sq(dddk[1]) + sq(dddk[2])));
+      const Recip Rnk = make_recip(fsqrt(sq(dddk[0]) + sq(dddk[1]) + sq(dddk[2])));
 #pragma unroll
       for (int i = 0; i < 3; i++) {
         dvds[i] = div(-sgn * dddk[i], Rnk);
@@ -1336,7 +1384,7 @@ RAYS_DEV void rhs_eval(const DevParams& P, const double v[NV], bool do_check, do
     cs_flag = eq.err;  // check_save.f90:41-43: flag text only
     // :53-57
     const double k3 = kvec[0] * eq.bunit[0] + kvec[1] * eq.bunit[1] + kvec[2] * eq.bunit[2];
-    const double k1 = sqrt(sq(kvec[0] - k3 * eq.bunit[0]) + sq(kvec[1] - k3 * eq.bunit[1]) +
+    const double k1 = fsqrt(sq(kvec[0] - k3 * eq.bunit[0]) + sq(kvec[1] - k3 * eq.bunit[1]) +
                            sq(kvec[2] - k3 * eq.bunit[2]));
     // residual :163-235
     const double n1 = div(k1, Rk0), n3 = div(k3, Rk0);

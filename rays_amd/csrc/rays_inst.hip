@@ -1,7 +1,9 @@
 // rays_inst.hip -- kernel instantiations.  Compiled once per (solver, equilibrium, derivative,
 // unit-exponent) group:
 //   -DRAYS_INST_SOLVER={0,1} -DRAYS_INST_EQ={0,1,2} -DRAYS_INST_DERIV={0,1} -DRAYS_INST_UE={0,1} -DRAYS_INST_MS={0,1}
-//   -DRAYS_INST_EQT=<EQ + 4 UE + 8 MS>  (the kernels' EQ template argument as a literal, for the kernel names)
+//   -DRAYS_INST_EQT=<EQ + 4 UE + 8 MS + 16 TOL>  (the kernels' EQ template argument as a literal, for the kernel names)
+//   -DRAYS_INST_TOL=1 -DRAYS_TOL_FLAVOUR -ffp-contract=fast: the tolerance flavour of a cold RK4 group
+//   (rays_device.hpp: kEqTol; 1e-10 relative per step instead of bit-identity)
 // Each group instantiates the species counts NS = 1..6 (nspec = 0..5, species_m.f90:25) and
 // nv = 7 | 12 (integrate_eq_gradients) and 8 | 13 (+ damping) (ode_m.f90:160-173); the MS = 1 groups
 // (multi_spec_damping) nv = 8 + NS | 13 + NS.
@@ -15,11 +17,20 @@
 #ifndef RAYS_INST_MS
 #define RAYS_INST_MS 0
 #endif
+#ifndef RAYS_INST_TOL
+#define RAYS_INST_TOL 0
+#endif
+#if RAYS_INST_TOL && !(defined(RAYS_TOL_FLAVOUR) && RAYS_INST_SOLVER == 0 && RAYS_INST_DERIV == 0 && RAYS_INST_MS == 0)
+#error "the tolerance flavour exists for the cold RK4 kernels only, compiled with -DRAYS_TOL_FLAVOUR"
+#endif
+#if !RAYS_INST_TOL && defined(RAYS_TOL_FLAVOUR)
+#error "-DRAYS_TOL_FLAVOUR without -DRAYS_INST_TOL=1: an exact kernel name would get tolerance arithmetic"
+#endif
 #define RAYS_CAT_(a, b, c, d, e, f) a##_##b##_##c##_##d##_##e##_##f
 #define RAYS_CAT(a, b, c, d, e, f) RAYS_CAT_(a, b, c, d, e, f)
 // the kernels' EQ template argument, as a literal (it appears in the kernel names rocprof prints)
 #ifndef RAYS_INST_EQT
-#error "pass -DRAYS_INST_EQT=<RAYS_INST_EQ + 4 RAYS_INST_UE + 8 RAYS_INST_MS>"
+#error "pass -DRAYS_INST_EQT=<RAYS_INST_EQ + 4 RAYS_INST_UE + 8 RAYS_INST_MS + 16 RAYS_INST_TOL>"
 #endif
 #define RAYS_STR_(x) #x
 #define RAYS_STR(x) RAYS_STR_(x)
@@ -28,16 +39,20 @@ namespace rays {
 
 namespace {
 constexpr int EQ = RAYS_INST_EQT;
-static_assert(EQ == (RAYS_INST_EQ | (RAYS_INST_UE ? kEqUnitExp : 0) | (RAYS_INST_MS ? kEqMultiSpec : 0)), "EQ encoding");
+static_assert(EQ == (RAYS_INST_EQ | (RAYS_INST_UE ? kEqUnitExp : 0) | (RAYS_INST_MS ? kEqMultiSpec : 0) |
+                     (RAYS_INST_TOL ? kEqTol : 0)), "EQ encoding");
 constexpr int DERIV = RAYS_INST_DERIV;
 
 template <int NS, int NV, int OCC = 1>
 hipError_t launch_one(const DevParams& P, const TraceArgs& A, hipStream_t stream, int* grid_blocks) {
 #if RAYS_INST_SOLVER == 0
   // (`if constexpr`: only the listed shapes get a two-waves-per-SIMD build compiled at all)
+#ifndef RAYS_HOST_EMUL
   if constexpr (OCC == 2) {
     return launch_persistent(rk4_trace_kernel_w2<EQ, NS, DERIV, NV>, 0, P, A, stream, grid_blocks);
-  } else {
+  } else
+#endif
+  {
 #ifdef RAYS_RK4_DIRECT_STORES
     constexpr size_t lds = 0;
 #else
@@ -79,7 +94,7 @@ const KernelEntry kEntries[] = {
 #endif
 #elif defined(RAYS_INST_FAST)  // developer builds (make FAST=1): electrons + one ion species only
     RAYS_ENTRY(2, 7), RAYS_ENTRY(2, 8),
-#if RAYS_INST_SOLVER == 0 && RAYS_INST_EQ != 2
+#if RAYS_INST_SOLVER == 0 && RAYS_INST_EQ != 2 && !defined(RAYS_HOST_EMUL)
     RAYS_ENTRY_OCC2(2, 7),
 #endif
 #else
@@ -109,7 +124,12 @@ extern "C" int RAYS_CAT(rays_debug_sg_profile, RAYS_INST_SOLVER, RAYS_INST_EQ, R
 }
 #endif
 
-const KernelEntry* RAYS_CAT(rays_entries, RAYS_INST_SOLVER, RAYS_INST_EQ, RAYS_INST_DERIV, RAYS_INST_UE, RAYS_INST_MS)(int* n) {
+#if RAYS_INST_TOL
+#define RAYS_ENTRIES_NAME rays_entries_tol
+#else
+#define RAYS_ENTRIES_NAME rays_entries
+#endif
+const KernelEntry* RAYS_CAT(RAYS_ENTRIES_NAME, RAYS_INST_SOLVER, RAYS_INST_EQ, RAYS_INST_DERIV, RAYS_INST_UE, RAYS_INST_MS)(int* n) {
   *n = (int)(sizeof(kEntries) / sizeof(kEntries[0]));
   return kEntries;
 }

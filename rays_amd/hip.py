@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = (
     "rays_hip_kernel_name", "rays_hip_kernel_name_for", "rays_hip_probe", "rays_hip_pack_device", "rays_hip_unpack_device",
     "rays_hip_sizeof_fan", "rays_hip_ray_init", "rays_hip_ray_init_device",
     "rays_hip_set_rho_table", "rays_hip_deposition_device", "rays_hip_deposition",
+    "rays_hip_set_numerics", "rays_hip_get_numerics",
 )
 
 _lib = None
@@ -108,6 +109,9 @@ def load():
     lib.rays_hip_deposition.argtypes = [pp, C.c_int, C.c_int, C.c_int, dp, ip, dp, dp, dp]
     lib.rays_hip_deposition_device.restype = C.c_int
     lib.rays_hip_deposition_device.argtypes = [pp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    lib.rays_hip_set_numerics.restype = C.c_int
+    lib.rays_hip_set_numerics.argtypes = [C.c_int]
+    lib.rays_hip_get_numerics.restype = C.c_int
     _lib = lib
     return lib
 
@@ -121,6 +125,23 @@ def last_error() -> str:
 def _check(rc: int, what: str):
     if rc != 0:
         raise RaysHipError(f"{what} failed (rc={rc}): {last_error()}")
+
+
+NUMERICS = {"exact": 0, "tolerance": 1}
+
+
+def set_numerics(mode: str) -> str:
+    """rays_hip_set_numerics: "exact" (bit-identical to the reference CPU path; default) or "tolerance" (north_star's
+    bar: 1e-10 relative per step, exact ray counts / step indices / stop flags; cold RK4 kernels).  Returns the
+    previous setting."""
+    prev = load().rays_hip_set_numerics(NUMERICS[mode])
+    if prev < 0:
+        raise RaysHipError("rays_hip_set_numerics: " + last_error())
+    return "tolerance" if prev == 1 else "exact"
+
+
+def get_numerics() -> str:
+    return "tolerance" if load().rays_hip_get_numerics() == 1 else "exact"
 
 
 def stop_flag_text(code: int) -> str:

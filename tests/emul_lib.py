@@ -40,7 +40,7 @@ def _build(sanitize, defs):
               "rays_ray_init.hpp", "rays_fan_setup.inc", "rays_deposition.hpp")]
     if os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs):
         return
-    cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+    cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-extern-tls-init", "-fPIC", "-shared",
            "-w", *defs, "-I", _DIR, srcs[0], "-o", _LIB]
     if sanitize:
         cmd[1:1] = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g"]

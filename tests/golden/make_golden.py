@@ -7,7 +7,13 @@ configs/, and cuts small fixtures (inputs + expected outputs, data only) from it
 Only runs where /root/reference was available to build the binary; the committed .npz files are
 what the tests read.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [fixture names ...]    (re)generate
+    python tests/golden/make_golden.py --check                 regenerate everything into a scratch directory and
+                                                               compare it with the committed files bit for bit
+
+The host-side spline tables next to the eqdsk file (configs/solovev_65x65.geqdsk.tables.npz, read by the Python
+host) are the UNION of what the eqdsk cases dump (each case's namelist selects its own profile splines: ne_* in
+one, te_* / ti_* in another); overlapping entries must agree bit for bit.
 """
 import os
 import shutil
@@ -99,7 +105,11 @@ def check_deterministic(cfg):
                  "(the reference races otherwise and the fixture would not be reproducible)")
 
 
-def results_file_fixture():
+TABLES = os.path.join("configs", "solovev_65x65.geqdsk.tables.npz")
+LD_FIXTURE = os.path.join("tests", "golden", "run_results.gold_slab4_ld")
+
+
+def results_file_fixture(out_root):
     """tests/golden/run_results.gold_slab4_ld: the reference's own write_results_LD output
     (ray_results_m.f90:365-420) for configs/gold_slab4_results_ld.in -- data for the writers of
     rays_amd/results.py."""
@@ -107,16 +117,36 @@ def results_file_fixture():
         shutil.copy(os.path.join(ROOT, "configs", "gold_slab4_results_ld.in"), os.path.join(d, "rays.in"))
         env = dict(os.environ, RAYS_DUMP_FILE="none", RAYS_DUMP_RESULTS_LD="1")
         subprocess.run([REF], cwd=d, env=env, check=True, stdout=subprocess.DEVNULL)
-        shutil.copy(os.path.join(d, "run_results.ld4"), os.path.join(ROOT, "tests", "golden", "run_results.gold_slab4_ld"))
+        shutil.copy(os.path.join(d, "run_results.ld4"), os.path.join(out_root, LD_FIXTURE))
     print("run_results.gold_slab4_ld")
 
 
-def main():
-    only = set(sys.argv[1:])  # optional: fixture names to (re)generate
-    if not os.path.exists(REF):
-        sys.exit("oracle/_ref/rays_ref_dump missing: run `bash oracle/build_ref.sh` first")
+def same_bits(a, b):
+    """Two arrays of a fixture: same dtype, shape and bytes (floats compared through their bit patterns)."""
+    a, b = np.asarray(a), np.asarray(b)
+    return a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+def merge_tables(merged, new, where):
+    """Union of the host tables of the eqdsk cases; an entry two cases both dump must be the same bits."""
+    for k, v in new.items():
+        v = np.asarray(v)
+        if k in merged:
+            if not same_bits(merged[k], v):
+                sys.exit(f"{where}: host table '{k}' differs from the one another eqdsk case dumped")
+        else:
+            merged[k] = v
+
+
+def generate(out_root, only=()):
+    """Cut the fixtures `only` (all when empty) into <out_root>/tests/golden and the merged host tables into
+    <out_root>/configs."""
+    only = set(only)
+    os.makedirs(os.path.join(out_root, "tests", "golden"), exist_ok=True)
+    os.makedirs(os.path.join(out_root, "configs"), exist_ok=True)
     if not only or "run_results.gold_slab4_ld" in only:
-        results_file_fixture()
+        results_file_fixture(out_root)
+    host_tabs = {}
     for name, cfg, subset, stride, nprobe in CASES:
         if only and name not in only:
             continue
@@ -156,12 +186,14 @@ def main():
         if axi is not None:
             for k, v in axi.items():
                 out["axi_" + k] = np.asarray(v)
-            # the same tables next to the eqdsk file, for the Python host (RaysRun.from_namelist)
-            host_tabs = {k: np.asarray(v) for k, v in axi.items()}
-            if dep is not None and "rho_grid" in dep:   # rho(psiN) spline, for the Ptotal_rho profile
-                host_tabs.update(rho_grid=dep["rho_grid"], rho_fspl=dep["rho_fspl"])
+            # the same tables next to the eqdsk file, for the Python host (RaysRun.from_namelist): merged over
+            # all eqdsk cases below (each namelist builds only the profile splines it selects)
             if len(axi["r_grid"]) and "psi_fspl" in axi:   # (analytic magnetics: profile tables only; bilinear: Python reads the eqdsk)
-                np.savez_compressed(os.path.join(ROOT, "configs", "solovev_65x65.geqdsk.tables.npz"), **host_tabs)
+                # a spline this namelist did not select is dumped empty: not an entry of the union
+                tabs = {k: np.asarray(v) for k, v in axi.items() if np.ndim(v) == 0 or np.size(v)}
+                if dep is not None and "rho_grid" in dep:   # rho(psiN) spline, for the Ptotal_rho profile
+                    tabs.update(rho_grid=dep["rho_grid"], rho_fspl=dep["rho_fspl"])
+                merge_tables(host_tabs, tabs, name)
         if dep is not None:
             # deposition profiles of the FULL fan + the full-fan trajectories they
             # are binned from (v(1:3), v(8)) so the device binner can be checked without a re-trace
@@ -179,10 +211,70 @@ def main():
             pr = ref["probes"]
             sel = np.linspace(0, len(pr) - 1, min(nprobe, len(pr))).astype(int)
             out["probes"] = pr[sel]
-        path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+        path = os.path.join(out_root, "tests", "golden", name + ".npz")
         np.savez_compressed(path, **out)
         print(f"{name}: nray={ref['nray']} kept={len(idx)} maxpts={keep} "
               f"steps={int((ref['npoints'] - 1).sum())} -> {os.path.getsize(path) / 1e3:.0f} kB")
+    if host_tabs:
+        dst = os.path.join(out_root, TABLES)
+        if only and os.path.exists(os.path.join(ROOT, TABLES)):
+            # a partial regeneration keeps what the cases not run contributed (same rule: overlaps must agree)
+            z = np.load(os.path.join(ROOT, TABLES))
+            merge_tables(host_tabs, {k: z[k] for k in z.files}, "committed " + TABLES)
+        np.savez_compressed(dst, **host_tabs)
+        print(f"{TABLES}: {sorted(host_tabs)}")
+
+
+def ld_records(path):
+    """Lines of a list-directed results file without the records that differ from run to run: the date and the
+    wall times (`date_vector`, `total_trace_time`, `ray_trace_time`; ray_results_m.f90:371-396)."""
+    volatile = {"date_vector", "total_trace_time", "ray_trace_time"}
+    names = {"RAYS_run_label", "date_vector", "number_of_rays", "max_number_of_points", "dim_v_vector", "npoints",
+             "total_trace_time", "initial_ray_power", "ray_trace_time", "end_ray_parameter", "end_residuals",
+             "max_residuals", "start_ray_vec", "end_ray_vec", "residual", "ray_vec", "ray_stop_flag"}
+    keep, skipping = [], False
+    for line in open(path):
+        t = line.strip()
+        if t in names:
+            skipping = t in volatile
+        if not skipping:
+            keep.append(line.rstrip())
+    return keep
+
+
+def check():
+    """Regenerate everything into a scratch directory and compare with the committed files bit for bit.
+    Returns the list of differences (empty = the committed tree is what this script produces)."""
+    diffs = []
+    with tempfile.TemporaryDirectory() as d:
+        generate(d)
+        for name in [c[0] + ".npz" for c in CASES]:
+            a, b = np.load(os.path.join(d, "tests", "golden", name)), np.load(os.path.join(ROOT, "tests", "golden", name))
+            if set(a.files) != set(b.files):
+                diffs.append(f"{name}: keys differ: only regenerated {sorted(set(a.files) - set(b.files))}, "
+                             f"only committed {sorted(set(b.files) - set(a.files))}")
+            diffs += [f"{name}: '{k}' differs" for k in sorted(set(a.files) & set(b.files)) if not same_bits(a[k], b[k])]
+        a, b = np.load(os.path.join(d, TABLES)), np.load(os.path.join(ROOT, TABLES))
+        if set(a.files) != set(b.files):
+            diffs.append(f"{TABLES}: keys differ: regenerated {sorted(a.files)}, committed {sorted(b.files)}")
+        diffs += [f"{TABLES}: '{k}' differs" for k in sorted(set(a.files) & set(b.files)) if not same_bits(a[k], b[k])]
+        if ld_records(os.path.join(d, LD_FIXTURE)) != ld_records(os.path.join(ROOT, LD_FIXTURE)):
+            diffs.append(f"{LD_FIXTURE}: differs beyond its date / wall-time records")
+    return diffs
+
+
+def main():
+    args = sys.argv[1:]
+    if not os.path.exists(REF):
+        sys.exit("oracle/_ref/rays_ref_dump missing: run `bash oracle/build_ref.sh` first")
+    if "--check" in args:
+        diffs = check()
+        for x in diffs:
+            print("DIFF", x)
+        print("make_golden --check:", "committed fixtures are what this script produces" if not diffs
+              else f"{len(diffs)} differences")
+        sys.exit(1 if diffs else 0)
+    generate(ROOT, args)  # optional: fixture names to (re)generate
 
 
 if __name__ == "__main__":

@@ -13,14 +13,15 @@
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
-#define __shared__
+#define __shared__ thread_local   /* `extern __shared__ double lds[]` = this host thread's rays::lds */
 #define __restrict__ __restrict
 
 struct emul_dim3 { unsigned x = 1, y = 1, z = 1; };
 extern thread_local emul_dim3 threadIdx, blockIdx, blockDim, gridDim;
+// (thread_local: the emulated C ABI traces on several host threads at once, one per device slot)
 #define RAYS_EMUL_DEFINE_GLOBALS \
   thread_local emul_dim3 threadIdx, blockIdx, blockDim, gridDim; \
-  namespace rays { double lds[1 << 16]; }
+  namespace rays { thread_local double lds[1 << 16]; }
 
 inline int __any(int x) { return x; }
 inline unsigned long long __ballot(int x) { return x ? 1ull : 0ull; }
@@ -31,3 +32,6 @@ inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 using std::copysign; using std::fabs; using std::fmax; using std::fmin; using std::ilogb;
 using std::pow; using std::scalbn; using std::sqrt; using std::exp;
+#ifdef RAYS_EMUL_RUNTIME
+#include "hip_runtime_api_emul.h"   // + the runtime API, for the emulated C ABI (emul_capi.cpp)
+#endif

@@ -72,6 +72,59 @@ def test_w2_solovev_fan_matches_oracle():
     _assert_same(out, ora)
 
 
+def _device_trace_sampled(p, r0, n0, stride):
+    """Trace the whole fan on the device, bring back only every `stride`-th ray (the full arrays of these fans are
+    6 - 34 GB) plus npoints / stop codes of all rays."""
+    import torch
+    from rays_amd.trace import DeviceTrace
+    tr = DeviceTrace(p, r0, n0)
+    tr.launch()
+    torch.cuda.synchronize()
+    sel = np.arange(0, len(r0), stride)
+    idx = torch.as_tensor(sel, device=tr.device)
+    out = {k: getattr(tr, k).index_select(0, idx).cpu().numpy() for k in ARRAYS}
+    npts, codes = tr.npoints.cpu().numpy(), tr.stop_code.cpu().numpy()
+    # zero past npoints and finite before it, over the whole fan, checked on the device
+    live = torch.arange(p.nstep_max + 1, device=tr.device)[None, :] < tr.npoints[:, None]
+    assert not bool((tr.residual * (~live)).any()) and not bool((tr.ray_vec * (~live)[..., None]).any())
+    assert bool(torch.isfinite(tr.residual).all())
+    del tr
+    torch.cuda.empty_cache()
+    return sel, out, npts, codes
+
+
+def test_w2_solovev_ragged_fan_with_refills_matches_oracle():
+    """The two-waves-per-SIMD build with what the lock-step fans above never reach: rays of their natural, ragged
+    lengths (99 .. 472 steps, nothing cut by nstep_max), more rays than resident lanes (512 x 400 = 204800 > 131072),
+    so lanes are refilled in the middle of their neighbours' steps and the delayed start of rays_rk4_body.inc (a
+    fresh ray waits for the lanes under way to come round to stage 3) is taken.  Every 256th ray against the
+    oracle, bit for bit."""
+    p, r0, n0 = _fan("cfg3b_solovev64k_rk4.in", {
+        "solovev_ray_init_nphi_ktheta_list": dict(n_rindex_theta=512, n_rindex_phi=400,
+                                                  delta_rindex_theta=0.32 / 512, delta_rindex_phi=0.4 / 400),
+        "ray_init_list": dict(nray_max=512 * 400),
+        "ode_list": dict(nstep_max=500)})
+    assert len(r0) >= 200000
+    assert hip.kernel_name(p, len(r0)) == "rk4_trace_kernel_w2<5, 2, 0, 7>"
+    sel, out, npts, codes = _device_trace_sampled(p, r0, n0, 256)
+    assert npts.max() - npts.min() > 200 and (codes == 2).mean() < 0.01       # natural lengths (ragged), not cut by nstep_max
+    ora = oracle_lib.trace(p, r0[sel], n0[sel], nthreads=os.cpu_count() or 1)
+    _assert_same(out, ora)
+
+
+def test_cfg4_full_size_w2_sampled_against_oracle():
+    """BASELINE config 4 at its full single-GPU size: the 1024 x 1024 = 1048576-ray slab fan, nstep_max = 500
+    (33.5 GB of trajectories, sixteen rays per resident lane) on `rk4_trace_kernel_w2<4, 2, 0, 7>`; every 4096th
+    ray against the oracle, bit for bit."""
+    p, r0, n0 = _fan("cfg4_slab1M_rk4.in", {})
+    assert len(r0) == 1024 * 1024
+    assert hip.kernel_name(p, len(r0)) == "rk4_trace_kernel_w2<4, 2, 0, 7>"
+    sel, out, npts, codes = _device_trace_sampled(p, r0, n0, 4096)
+    assert int((npts.astype(np.int64) - 1).sum()) == 524242966               # DESIGN 7: steps per pass
+    ora = oracle_lib.trace(p, r0[sel], n0[sel], nthreads=os.cpu_count() or 1)
+    _assert_same(out, ora)
+
+
 def _tiled(r0, n0, nray):
     reps = nray // len(r0) + 1
     return np.tile(r0, (reps, 1))[:nray].copy(), np.tile(n0, (reps, 1))[:nray].copy()

@@ -1,0 +1,165 @@
+"""GPU tier: the TOLERANCE flavour of the cold RK4 kernels (rays_hip_set_numerics(RAYS_NUMERICS_TOLERANCE):
+`rk4_trace_kernel[_w2]<EQ | 16, ...>`, FMA contraction + once-refined reciprocals and roots) against the bar
+BASELINE.json's north_star states -- every step within 1e-10 relative of the reference's, ray counts / step
+indices / stop flags EXACTLY the reference's:
+
+  * per step: the flavour restarted from every recorded reference point of every RK4 / cold fixture for one output
+    step (ode_solver + check_save) lands within 1e-10 (norm-wise on r and k) of the reference's next point;
+  * counts: npoints and stop codes of the fixtures and of the FULL fans of BASELINE configs 2, 3b (the headline,
+    65536 rays), 4 (131769 rays, two-waves build) and 5b (262144 rays) equal the oracle's on every ray;
+  * accumulated trajectories stay within 1e-6 of the reference's over a whole ray (not part of the contract --
+    errors of 1e-16 per step grow along rays that graze a cutoff -- but a regression alarm).
+
+Everything else (finite-difference dD, SG, multi_spec_damping) runs the exact kernels under either setting."""
+import os
+
+import numpy as np
+import pytest
+
+from rays_amd import hip
+from tests import oracle_lib
+from tests.common import GOLDEN_CASES, assert_matches_golden, load_golden, stop_codes
+from tests.test_gpu_baseline_kernels import _fan
+
+pytestmark = pytest.mark.gpu
+
+PER_STEP_TOL = 1e-10   # north_star
+ACCUMULATED_TOL = 1e-6
+
+
+@pytest.fixture(autouse=True)
+def tolerance_numerics():
+    prev = hip.set_numerics("tolerance")
+    yield
+    hip.set_numerics(prev)
+
+
+def _has_flavour(p):
+    return p.ode_solver == 0 and p.ray_deriv == 0 and not p.multi_spec_damping
+
+
+def _flavour_cases():
+    from rays_amd.namelist import read_namelist
+    out = []
+    for name in GOLDEN_CASES:
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+        nml = read_namelist(os.path.join(os.path.dirname(__file__), "..", "configs", str(g["config"])))
+        ode = nml.get("ode_list", {})
+        if str(ode.get("ode_solver_name", "")).strip().upper() == "RK4_ODE" and \
+                str(ode.get("ray_deriv_name", "cold")).strip() == "cold" and \
+                not nml.get("damping_list", {}).get("multi_spec_damping", False):
+            out.append(name)
+    return out
+
+
+CASES = _flavour_cases()
+
+
+def test_there_are_flavour_fixtures():
+    assert len(CASES) >= 15, CASES
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_fixture_counts_exact_and_trajectories_close(name):
+    g, nml, p = load_golden(name)
+    assert _has_flavour(p)
+    k = hip.kernel_name(p)
+    eq = int(k.split("<")[1].split(",")[0])
+    assert eq & 16, f"{k}: not the tolerance flavour"
+    out = hip.trace_host(p, g["rvec0"], g["rindex_vec0"], ngpu=1)
+    np.testing.assert_array_equal(out["npoints"], g["npoints"])
+    np.testing.assert_array_equal(out["stop_code"], stop_codes(g["stop_flag"]))
+    assert_matches_golden(out, g, p, rel_tol=ACCUMULATED_TOL, resid_atol=1e-9)
+
+
+def _rel(a, b, sl):
+    num = np.linalg.norm(a[:, sl] - b[:, sl], axis=-1)
+    den = np.linalg.norm(b[:, sl], axis=-1)
+    m = den > 0
+    return float((num[m] / den[m]).max()) if m.any() else 0.0
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_per_step_within_1e10_of_the_reference(name):
+    """north_star: "within 1e-10 relative per step"."""
+    g, nml, p = load_golden(name)
+    ref, npts = g["ray_vec"], g["npoints"]
+    v0, v1, s0 = [], [], []
+    for r in range(len(npts)):
+        n = int(npts[r])
+        if n < 2:
+            continue
+        s = np.concatenate([[0.0], np.cumsum(np.full(n - 1, float(p.ds)))])
+        v0.append(ref[r, :n - 1])
+        v1.append(ref[r, 1:n])
+        s0.append(s[:n - 1])
+    if not v0:
+        pytest.skip("no ray of this fixture takes a step")
+    v0, v1, s0 = np.concatenate(v0), np.concatenate(v1), np.concatenate(s0)
+    got, resid, code = hip.ode_step(p, v0, s0)
+    assert (code == 0).all(), f"{(code != 0).sum()} of {len(code)} restarted steps stopped: {np.unique(code)}"
+    worst = max(_rel(got, v1, slice(0, 3)), _rel(got, v1, slice(3, 6)))
+    assert worst <= PER_STEP_TOL, f"per-step rel err {worst:.3e}"
+    # the other rows (ray parameter, absorbed power, equilibrium gradients): relative to the row's magnitude
+    damp = bool(p.damping_model)
+    for c in range(6, p.nv):
+        scale = max(np.abs(v1[:, c]).max(), 1e-300)
+        tol = 1e-6 if (damp and c == 7) else PER_STEP_TOL   # v(8): k_i goes through single-precision COMPLEX in the reference
+        assert np.abs(got[:, c] - v1[:, c]).max() <= tol * scale, f"row {c}"
+
+
+def _oracle_counts(p, r0, n0, chunk=4096):
+    npts, codes = [], []
+    for i in range(0, len(r0), chunk):
+        o = oracle_lib.trace(p, r0[i:i + chunk], n0[i:i + chunk], nthreads=os.cpu_count() or 1)
+        npts.append(o["npoints"])
+        codes.append(o["stop_code"])
+    return np.concatenate(npts), np.concatenate(codes)
+
+
+def _device_counts(p, r0, n0):
+    import torch
+    from rays_amd.trace import DeviceTrace
+    tr = DeviceTrace(p, r0, n0)
+    tr.launch()
+    torch.cuda.synchronize()
+    out = tr.npoints.cpu().numpy(), tr.stop_code.cpu().numpy()
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
+FULL_FANS = [
+    ("cfg2_solovev1024_rk4.in", {}, "rk4_trace_kernel<21, 2, 0, 7>"),
+    ("cfg3b_solovev64k_rk4.in", {}, "rk4_trace_kernel<21, 2, 0, 7>"),
+    ("cfg4_slab1M_rk4.in", {"simple_slab_ray_init_list": dict(n_ky_launch=363, n_kz_launch=363, delta_rindex_y0=0.2 / 363,
+                                                               delta_rindex_z0=0.2 / 363)}, "rk4_trace_kernel_w2<20, 2, 0, 7>"),
+    ("cfg5b_axisym256k_rk4_damp.in", {}, "rk4_trace_kernel<22, 2, 0, 8>"),
+]
+
+
+@pytest.mark.parametrize("cfg,overrides,kernel", FULL_FANS)
+def test_full_fan_counts_are_exactly_the_oracles(cfg, overrides, kernel):
+    """npoints and stop codes of EVERY ray of the full fan equal the oracle's (which is bit-identical to the
+    reference): the flavour is only acceptable if not one count flips."""
+    tab = None
+    if "axisym" in cfg:
+        g, _, _ = load_golden("gold_axisym64_eqdsk_damp_sg")
+        tab = {k[4:]: (float(g[k]) if g[k].ndim == 0 else g[k]) for k in g.files if k.startswith("axi_")}
+    p, r0, n0 = _fan(cfg, overrides, tables=tab)
+    assert hip.kernel_name(p, len(r0)) == kernel
+    npts, codes = _device_counts(p, r0, n0)
+    o_npts, o_codes = _oracle_counts(p, r0, n0)
+    bad = np.flatnonzero((npts != o_npts) | (codes != o_codes))
+    assert len(bad) == 0, f"{len(bad)} of {len(r0)} rays differ in npoints / stop code, first: {bad[:10]}"
+
+
+def test_exact_is_the_default_and_other_configs_keep_their_exact_kernels():
+    assert hip.get_numerics() == "tolerance"
+    for name in ("gold_solovev64_rk4_num", "gold_solovev64_sg_cold", "gold_slab16_damp_multi_grad_rk4"):
+        g, nml, p = load_golden(name)
+        eq = int(hip.kernel_name(p).split("<")[1].split(",")[0])
+        assert not eq & 16, hip.kernel_name(p)
+    hip.set_numerics("exact")
+    g, nml, p = load_golden("cfg2_solovev1024_rk4")
+    assert hip.kernel_name(p) == "rk4_trace_kernel<5, 2, 0, 7>"
