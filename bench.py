@@ -41,31 +41,82 @@ N_SIMD = 256 * 4         # 256 CUs x 4 SIMDs
 FP64_CLK_PER_WAVE_INST = 4  # a wave64 FP64 VALU instruction occupies its SIMD's 16 lanes for 4 clocks
 
 
+def visible_gpu_count():
+    """GPUs this process would see, WITHOUT initialising HIP in it (the parent of a self-launched run never touches
+    a GPU): the visibility variables if set, else the KFD topology (nodes with SIMDs are GPUs)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n = 0
+    top = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(top):
+            for line in open(os.path.join(top, node, "properties")):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+    except OSError:
+        return None   # no KFD here: let the ranks find out
+    return n
+
+
 def self_launch(args):
     """`--gpus N` with no launcher: start the N ranks as child processes (the parent has not touched a GPU
-    and never will), relay rank 0's stdout, exit with the worst return code."""
+    and never will), relay rank 0's stdout, exit with the worst return code.  A rank that dies takes its
+    siblings with it (they would otherwise sit in a rendezvous or a barrier until its timeout)."""
     import socket
 
-    import torch
-
-    ndev = torch.cuda.device_count()   # counting devices does not initialise the GPU
-    if ndev < args.gpus and not os.environ.get("RAYS_BENCH_SHARE_GPU"):
+    ndev = visible_gpu_count()
+    if ndev is not None and ndev < args.gpus and not os.environ.get("RAYS_BENCH_SHARE_GPU"):
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible "
                          "(RAYS_BENCH_SHARE_GPU=1 rehearses N ranks on fewer GPUs)")
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    rcs = [pr.wait() for pr in procs]
-    sys.stdout.write(out0)
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    rcs = [None] * len(procs)
+    while any(rc is None for rc in rcs):
+        for i, pr in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = pr.poll()
+        if any(rc not in (None, 0) for rc in rcs):     # one rank failed: end the others now
+            for i, pr in enumerate(procs):
+                if rcs[i] is None:
+                    pr.terminate()
+            for i, pr in enumerate(procs):
+                if rcs[i] is None:
+                    try:
+                        rcs[i] = pr.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        pr.kill()
+                        rcs[i] = pr.wait()
+            break
+        time.sleep(0.2)
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
     raise SystemExit(max(abs(rc) for rc in rcs))
+
+
+def kernel_source_hash():
+    """sha256 over the sources librays_hip.so is built from (rays_amd/csrc + the C ABI header): profiles/counters.json
+    records it when its counters are collected, and a bench run whose sources hash differently reports no counter-
+    derived figures (the counters would describe another kernel)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rays_amd", "csrc")
+    files = sorted(f for f in os.listdir(d) if f.endswith((".hpp", ".inc", ".hip")) or f == "Makefile")
+    for f in files + [os.path.join("..", "..", "include", "rays_hip.h")]:
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_model():
@@ -240,6 +291,11 @@ def main():
     ap.add_argument("--fan-scale", type=int, default=1,
                     help="diagnostic: rays per GPU = 65536 x this (finer n_theta); not the headline config")
     ap.add_argument("--nstep-max", type=int, default=None, help="diagnostic: override nstep_max")
+    ap.add_argument("--numerics", choices=("tolerance", "exact"), default="tolerance",
+                    help="rays_hip_set_numerics: 'tolerance' = north_star's bar (every step within 1e-10 relative of the "
+                         "reference's, ray counts / step indices / stop flags exactly the reference's; cold RK4 kernels) "
+                         "| 'exact' = bit-identical to the reference CPU path.  The line names what ran (config.kernel, "
+                         "config.numerics) and, on one GPU, carries the other flavour's rate as value_exact")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -270,6 +326,7 @@ def main():
         backend = os.environ.get("RAYS_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
         dist.init_process_group(backend, device_id=dev if backend == "nccl" else None)
 
+    hip.set_numerics(args.numerics)
     nml, p, r0, n0 = build_fan(args.config, world, args.fan_scale, args.nstep_max)
     nray_total = len(r0)
     from rays_amd.exchange import shard_bounds
@@ -371,6 +428,8 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     n_ranks_seen = int(ones.item())
     total_steps = int(tot.item())
+    if n_ranks_seen != args.gpus:   # never report an N-GPU line that fewer ranks produced
+        raise SystemExit(f"bench.py --gpus {args.gpus}: the collective saw {n_ranks_seen} rank(s)")
     split = {}
     if world > 1 and gather is not None:
         el_trace, _ = timed(args.steps, with_exchange=False)        # the same K passes without the exchange
@@ -392,12 +451,34 @@ def main():
                      gather_ms=1e3 * gather_s, gather_bytes_per_peer=peer_bytes,
                      gather_GBps_per_peer=peer_bytes / gather_s / 1e9,
                      gather_GBps_into_root=peer_bytes * (world - 1) / gather_s / 1e9,
+                     scaling_bound="root ingest: every pass each of the N-1 peers sends its packed trajectories (gather_bytes_per_peer) "
+                                   "to rank 0 over its own xGMI link (~77 GB/s per direction), so ms_per_step >= max(trace, "
+                                   "gather_bytes_per_peer / link rate) for every N >= 2 and value levels off near "
+                                   "N x recorded_steps / that time (DESIGN.md 5); value_trace_only is what the kernels scale to",
+                     modelled_gather_floor_ms=1e3 * peer_bytes / 77e9,
                      gather_note="value = trace + gather as the metric is defined (the exchange of pass i runs behind the "
                           "trace of pass i+1, so ms_per_step ~ max(trace, gather)); value_trace_only = the same K "
                           "passes with the exchange switched off; gather_ms = one exchange on its own")
 
     # the timed passes must have reproduced the first pass (deterministic kernels)
     assert int(torch.clamp(tr.npoints.to(torch.int64) - 1, min=0).sum().item()) == steps_local
+
+    # ---- the other numerics flavour of the same kernel, same K passes (one GPU; outside the timed region) ----
+    other = None
+    if world == 1 and args.exchange == "gather":
+        this_kernel = hip.kernel_name(p, hi - lo)
+        hip.set_numerics("exact" if args.numerics == "tolerance" else "tolerance")
+        if hip.kernel_name(p, hi - lo) != this_kernel:   # (configurations without a tolerance flavour run one kernel)
+            npts_before = tr.npoints.clone()
+            step()
+            el_o, k_o = timed(args.steps)
+            same_counts = bool(torch.equal(npts_before, tr.npoints))
+            tag = "exact" if args.numerics == "tolerance" else "tolerance"
+            other = {f"value_{tag}": total_steps / (el_o / args.steps), f"ms_per_step_{tag}": 1e3 * el_o / args.steps,
+                     f"kernel_{tag}": hip.kernel_name(p, hi - lo), "flavours_agree_on_npoints": same_counts}
+        hip.set_numerics(args.numerics)
+        tr.launch(zero_fill=False)     # leave the arrays as the timed flavour wrote them
+        torch.cuda.synchronize()
 
     if rank == 0 and gather is not None and args.verify_gather:
         full = DeviceTrace(p, r0, n0, device=dev)
@@ -417,10 +498,18 @@ def main():
         # profiles/counters.json = {config file name: {hbm_bytes_per_launch, fp64_wave_insts: {...}, ...}}
         traffic, fp64 = None, None
         cpath = os.path.join(ROOT, "profiles", "counters.json")
+        kname = hip.kernel_name(p, hi - lo)
         if os.path.exists(cpath) and args.fan_scale == 1 and args.nstep_max is None:
             try:
-                c = json.load(open(cpath)).get(os.path.basename(args.config))
-                if c and c.get("kernel") == hip.kernel_name(p, hi - lo):
+                db = json.load(open(cpath))
+                c = db.get(os.path.basename(args.config) + "::" + kname)
+                src_now = kernel_source_hash()
+                if c and c.get("source_hash") != src_now:
+                    print(f"[bench] profiles/counters.json: counters of {kname} were collected from other kernel sources "
+                          f"({c.get('source_hash')} != {src_now}): roofline.traffic / roofline_fp64 omitted -- re-run "
+                          "tools/profile_bench.sh + tools/update_counters.py", file=sys.stderr)
+                    c = None
+                if c and c.get("kernel") == kname:
                     traffic = c.get("hbm_bytes_per_launch")
                     w = c.get("fp64_wave_insts")
                     if w:
@@ -449,6 +538,11 @@ def main():
                        "ode": "RK4_ODE" if p.ode_solver == 0 else "SG_ODE",
                        "deriv": "cold" if p.ray_deriv == 0 else "numerical",
                        "kernel": hip.kernel_name(p, hi - lo),
+                       "numerics": (hip.get_numerics() + (": every step within 1e-10 relative of the reference's, ray counts / "
+                                    "step indices / stop flags exactly the reference's (tests/test_gpu_tolerance_flavour.py)"
+                                    if hip.get_numerics() == "tolerance" and "<" in hip.kernel_name(p, hi - lo) and
+                                    int(hip.kernel_name(p, hi - lo).split("<")[1].split(",")[0]) & 16
+                                    else ": bit-identical to the reference CPU path")),
                        "exchange": ("none" if world == 1 else
                                     ("skipped" if args.no_gather else "packed send/recv to rank 0 (RCCL)"))
                        if args.exchange == "gather" else
@@ -466,6 +560,8 @@ def main():
         if idle is not None:
             line["simd_idle_frac"] = idle
         line.update(split)
+        if other is not None:
+            line.update(other)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(line))

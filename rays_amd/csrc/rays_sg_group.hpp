@@ -1,0 +1,948 @@
+// rays_sg_group.hpp -- Shampine-Gordon ray-trace kernel with ONE RAY PER GROUP OF G LANES, for the finite-difference
+// dispersion derivatives (ode_solver_name = 'SG_ODE', ray_deriv_name = 'numerical', nv = 7: BASELINE config 3).
+//
+// Reference path restated here: the same as rays_sg.hpp (trace_rays ray_tracing.f90:67-264, SG_ode SG_ode_m.f90:89-159,
+// ode/de/step/intrp ode_RAYS.f90) + deriv_num (deriv_num.f90:1-155).
+//
+// Why another mapping.  With one ray per lane (rays_sg.hpp) an evaluation of the right-hand side is TWENTY
+// sub-evaluations run one after the other in the lane -- deriv_num's fourteen determinants, six of them at perturbed
+// equilibria, two at perturbed frequencies (deriv_num.f90:40-84) -- and the Adams integrator around it keeps
+// phi(7,16) and six coefficient vectors per lane: 256 VGPRs + ~200 AGPRs + all of the LDS + a global workspace, one
+// wave per SIMD, ~13 clocks per bookkeeping instruction (nothing hides an LDS round trip), and a 65536-ray fan is
+// exactly one ray per resident lane: nothing to refill, the pass lasts as long as its longest ray while half the
+// SIMDs idle.  Here a ray owns G = 8 lanes:
+//   * lane j of the group evaluates the j-th central difference of deriv_num -- two determinants at two
+//     equilibria, the same code in every lane on different data (d/dx, d/dy, d/dz, d/dkx, d/dky, d/dkz, d/domega;
+//     the eighth lane evaluates the unperturbed equilibrium for the box test) -- and the seven differences are
+//     exchanged with __shfl; a right-hand side is 2 sub-evaluations deep instead of 20;
+//   * lane j also owns component j of the ODE vector: its row of the divided differences phi(j, 1:16) is SIXTEEN
+//     doubles in registers (no tiers, no workspace, no AGPR parking); predictor, corrector and difference updates
+//     (ode_RAYS.f90:985-1011, 1128-1164) are one operation per lane instead of seven, the weighted norms of `step`
+//     are gathered in the reference's summation order;
+//   * the scalar part of `step` (order and step-size selection, the coefficient recurrences psi, alpha, beta, sig,
+//     g, v) is replicated in the group's lanes; the coefficient vectors live in one LDS column per RAY (672 bytes);
+//   * a wave holds 8 rays and needs ~1/3 of the registers, so several waves share a SIMD (their LDS round trips
+//     overlap) and a 64k fan is 8192 waves: finished groups pull the next ray, the idle tail is gone.
+// Every floating-point operation is the reference's, in its order: results are bit-identical to rays_sg.hpp's
+// and to the reference (tests/test_cpu_group_emul.py on the host wave emulator, tests/test_gpu_*).
+//
+// Cross-lane operations (__any, __ballot, __shfl) are only issued from wave-uniform control flow.
+#pragma once
+
+#include "rays_sg.hpp"
+
+namespace rays {
+
+template <int G>
+struct GrpGeom {
+  static_assert(G == 4 || G == 8 || G == 16, "lanes per ray");
+  static constexpr int NV = 7;
+  static constexpr int CPL = (NV + 1 + G - 1) / G;  // per lane: ODE components = difference pairs (7 + the base point)
+  static constexpr int kBaseLane = NV % G, kBaseSlot = NV / G;  // who holds "pair 7", the unperturbed equilibrium
+  static constexpr int kRaysPerBlock = kBlock / G;
+  static constexpr int kCoefLen = 14, kCoefArrays = 6;
+  static constexpr size_t kLdsBytes = (size_t)kCoefArrays * kCoefLen * kRaysPerBlock * sizeof(double);
+};
+
+// value held by lane j of this lane's group (all lanes of the wave take part)
+template <int G>
+RAYS_DEV double grp_bcast(double x, int j) { return __shfl(x, j, G); }
+template <int G>
+RAYS_DEV int grp_bcast(int x, int j) { return __shfl(x, j, G); }
+// sum over the ODE components in the reference's order l = 1..7 (component l lives in slot l / G of lane l % G)
+template <int G>
+RAYS_DEV double grp_sum(const double t[GrpGeom<G>::CPL]) {
+  double s = 0.;
+#pragma unroll
+  for (int l = 0; l < 7; l++) s = s + grp_bcast<G>(t[l / G], l % G);
+  return s;
+}
+
+// The coefficient vectors of `step` (psi, alpha, beta, sig, g, v; ode_RAYS.f90:662-672), one LDS column per ray.
+// Every lane of the group computes the same values and writes them (same address, same data); a lane only ever
+// reads back what it wrote itself.
+struct GCoef {
+  enum { PSI = 0, ALPHA, BETA, SIG, GG, V };
+  sg_lds_ptr col;
+  int stride;
+  struct Ref {
+    sg_lds_ptr p;
+    RAYS_DEV operator double() const { return *p; }
+    RAYS_DEV const Ref& operator=(double x) const { *p = x; return *this; }
+    RAYS_DEV const Ref& operator=(const Ref& o) const { return *this = (double)o; }
+  };
+  RAYS_DEV Ref at(int arr, int i) const { return Ref{col + (arr * 14 + i - 1) * stride}; }
+  RAYS_DEV Ref psi(int i) const { return at(PSI, i); }      // 1..12
+  RAYS_DEV Ref alpha(int i) const { return at(ALPHA, i); }  // 1..12
+  RAYS_DEV Ref beta(int i) const { return at(BETA, i); }    // 1..12
+  RAYS_DEV Ref sig(int i) const { return at(SIG, i); }      // 1..13
+  RAYS_DEV Ref g(int i) const { return at(GG, i); }         // 1..13
+  RAYS_DEV Ref v(int i) const { return at(V, i); }          // 1..12
+  RAYS_DEV Ref wi(int i) const { return at(ALPHA, i); }     // intrp's w(1:14) reuses alpha (the integrator restarts after it)
+  RAYS_DEV Ref gi(int i) const { return at(SIG, i); }       // intrp's g(1:13) reuses sig
+};
+
+// This lane's rows of the divided differences: phi(l, 1:16) for its C components, all in registers.  Rows are indexed
+// by the ray's order, so every loop over rows is unrolled with the ray's bounds as predicates; `cap` is a
+// wave-uniform bound on the row index (the largest order in the wave + what the caller adds), so the unrolled loops
+// end with a scalar branch.
+template <int C>
+struct GPhi {
+  double r[17][C];  // [1..16]
+  RAYS_DEV void clear() {
+#pragma unroll
+    for (int q = 0; q < 17; q++)
+#pragma unroll
+      for (int c = 0; c < C; c++) r[q][c] = 0.;
+  }
+  RAYS_DEV void get(int i, double out[C], int cap) const {  // out = phi(:, i); i outside 1..14: zeros
+#pragma unroll
+    for (int c = 0; c < C; c++) out[c] = 0.;
+#pragma unroll
+    for (int q = 1; q <= 14; q++) {
+      if (q > cap) break;
+      if (i == q) {
+#pragma unroll
+        for (int c = 0; c < C; c++) out[c] = r[q][c];
+      }
+    }
+  }
+  RAYS_DEV void set(int i, const double in[C], int cap) {
+#pragma unroll
+    for (int q = 1; q <= 14; q++) {
+      if (q > cap) break;
+      if (i == q) {
+#pragma unroll
+        for (int c = 0; c < C; c++) r[q][c] = in[c];
+      }
+    }
+  }
+  // phi(:, i) = beta(i) * phi(:, i), i = a..b                       (ode_RAYS.f90:992-996)
+  RAYS_DEV void scale(int a, int b, const GCoef& S, int cap) {
+#pragma unroll
+    for (int q = 1; q <= 12; q++) {
+      if (q > cap) break;
+      if (q >= a && q <= b) {
+        const double bq = S.beta(q);
+#pragma unroll
+        for (int c = 0; c < C; c++) r[q][c] = bq * r[q][c];
+      }
+    }
+  }
+  // predictor (:1003-1011), i = k..1:  p += phi(:,i)*g(i); phi(:,i) += phi(:,i+1)   (phi(:,k+1) has just been zeroed)
+  RAYS_DEV void predict(int k, const GCoef& S, double pp[C], int cap) {
+    double up[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) up[c] = 0.;
+#pragma unroll
+    for (int q = 12; q >= 1; q--) {
+      if (q > cap) continue;
+      if (q <= k) {
+        const double gg = S.g(q);
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          double x = r[q][c];
+          pp[c] = pp[c] + x * gg;
+          x = x + up[c];
+          r[q][c] = x;
+          up[c] = x;
+        }
+      }
+    }
+  }
+  // failed step (:1090-1094), i = 1..k ascending:  phi(:,i) = (phi(:,i) - phi(:,i+1)) / beta(i)
+  RAYS_DEV void restore(int k, const GCoef& S, int cap) {
+#pragma unroll
+    for (int q = 1; q <= 12; q++) {
+      if (q > cap) break;
+      if (q <= k) {
+        const Recip b = make_recip(S.beta(q));
+#pragma unroll
+        for (int c = 0; c < C; c++) r[q][c] = div(r[q][c] - r[q + 1][c], b);
+      }
+    }
+  }
+  // phi(:, i) += d, i = 1..k                                         (:1160-1164)
+  RAYS_DEV void add(int k, const double d[C], int cap) {
+#pragma unroll
+    for (int q = 1; q <= 12; q++) {
+      if (q > cap) break;
+      if (q <= k) {
+#pragma unroll
+        for (int c = 0; c < C; c++) r[q][c] = r[q][c] + d[c];
+      }
+    }
+  }
+  // intrp (:1343-1349), i = ki..1:  yout += g(i) * phi(:, i)
+  RAYS_DEV void interp(int ki, const GCoef& S, double yout[C], int cap) const {
+#pragma unroll
+    for (int q = 13; q >= 1; q--) {
+      if (q > cap) continue;
+      if (q <= ki) {
+        const double gg = S.gi(q);
+#pragma unroll
+        for (int c = 0; c < C; c++) yout[c] = yout[c] + gg * r[q][c];
+      }
+    }
+  }
+};
+
+// Equilibrium for determ at a (possibly perturbed) point; returns the equilibrium's stop code when check_box is set
+// (the group's base lane: equilibrium_m.f90:198-202, eqn_ray.f90:90-102).
+template <int EQ, int NS>
+RAYS_DEV int eq_for_determ_err(const DevParams& P, const Recip& Romgrf, const Recip& Romgrf2, const double rvec[3],
+                               double bunit[3], double alpha[NS], double gamma[NS], bool check_box) {
+  EqPoint<NS> e;
+  equilibrium<EQ, NS>(P, Romgrf, Romgrf2, rvec, e, check_box);
+#pragma unroll
+  for (int i = 0; i < 3; i++) bunit[i] = e.bunit[i];
+#pragma unroll
+  for (int is = 0; is < NS; is++) {
+    alpha[is] = e.alpha[is];
+    gamma[is] = e.gamma[is];
+  }
+  return e.err;
+}
+
+// ONE evaluation of eqn_ray (ray_deriv_name = 'numerical') for the group's ray, optionally with check_save at the
+// same state.  win: this lane's components of the state.  f: this lane's components of dv/ds.  The other outputs are
+// the same in every lane of the group.  Call from wave-uniform control flow.
+//   deriv_num.f90:40-84: dddx(i) = (D(r + delta e_i) - D(r - delta e_i)) / (2 delta), dddk(i) likewise with
+//   change = max(delta, |delta k_i|) / 2, dddw from omgrf (1 +- delta/2) with k0 rescaled; D = determ (:99-153).
+template <int EQ, int NS, int G>
+RAYS_DEV void group_rhs(const DevParams& P, const double win[GrpGeom<G>::CPL], int gl, bool do_check, bool any_check,
+                        double f[GrpGeom<G>::CPL], int& code, double& resid, int& cs_flag, bool& cs_stop) {
+  typedef GrpGeom<G> GEO;
+  constexpr int C = GEO::CPL;
+  double v[7];
+#pragma unroll
+  for (int l = 0; l < 7; l++) v[l] = grp_bcast<G>(win[l / G], l % G);
+  const double rvec[3] = {v[0], v[1], v[2]}, kvec[3] = {v[3], v[4], v[5]};
+  double d[C];
+  int err_base = 0;
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    const int p = gl + G * c;  // 0..2: d/dx_p   3..5: d/dk_(p-3)   6: d/domega   7: the unperturbed point (box test)   > 7: none
+    double rp[3], rm[3], kp[3], km[3], two_change = 0.;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      rp[i] = (p == i) ? rvec[i] + P.delta : rvec[i];  // :42-43
+      rm[i] = (p == i) ? rvec[i] - P.delta : rvec[i];  // :48
+      const double change = fmax(P.delta, fabs(P.delta * kvec[i])) / 2.;  // :61
+      kp[i] = (p == 3 + i) ? kvec[i] + change : kvec[i];
+      km[i] = (p == 3 + i) ? kvec[i] - change : kvec[i];
+      if (p == 3 + i) two_change = 2. * change;
+    }
+    const bool w = p == 6;  // :71-80: per-lane omgrf / k0 (the reference rewrites its module variables)
+    const Recip Rop = const_recip(w ? P.omgrf_p : P.omgrf, w ? P.inv_omgrf_p : P.inv_omgrf);
+    const Recip Rop2 = const_recip(w ? P.omgrf2_p : P.omgrf2, w ? P.inv_omgrf2_p : P.inv_omgrf2);
+    const Recip Rkp = const_recip(w ? P.k0_p : P.k0, w ? P.inv_k0_p : P.inv_k0);
+    const Recip Rom = const_recip(w ? P.omgrf_m : P.omgrf, w ? P.inv_omgrf_m : P.inv_omgrf);
+    const Recip Rom2 = const_recip(w ? P.omgrf2_m : P.omgrf2, w ? P.inv_omgrf2_m : P.inv_omgrf2);
+    const Recip Rkm = const_recip(w ? P.k0_m : P.k0, w ? P.inv_k0_m : P.inv_k0);
+    double bu[3], al[NS], ga[NS];
+    const int e1 = eq_for_determ_err<EQ, NS>(P, Rop, Rop2, rp, bu, al, ga, p == 7);
+    const double det_plus = determ<NS>(bu, al, ga, kp, Rkp);
+    (void)eq_for_determ_err<EQ, NS>(P, Rom, Rom2, rm, bu, al, ga, false);
+    const double det_minus = determ<NS>(bu, al, ga, km, Rkm);
+    const double den = p < 3 ? P.two_delta : (p < 6 ? two_change : P.omgrf0_delta);
+    d[c] = (det_plus - det_minus) / den;  // :50, :63, :80
+    if (p == 7) err_base = e1;
+  }
+  double dd[7];
+#pragma unroll
+  for (int p = 0; p < 7; p++) dd[p] = grp_bcast<G>(d[p / G], p % G);
+  const int err = grp_bcast<G>(err_base, GEO::kBaseLane);
+  const double dddx[3] = {dd[0], dd[1], dd[2]}, dddk[3] = {dd[3], dd[4], dd[5]};
+  double dvds[7];
+#pragma unroll
+  for (int l = 0; l < 7; l++) dvds[l] = 0.;
+  EqPoint<NS> eq_unused;  // (ray_equations reads it for the damping / gradient rows only; nv = 7 has neither)
+  eq_unused.err = 0;
+  const int rc = ray_equations<NS, 7, false>(P, eq_unused, kvec, 0., dddx, dddk, dd[6], dvds);
+  code = err ? err : rc;  // eqn_ray.f90:90-102 returns before the derivatives
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    f[c] = 0.;
+#pragma unroll
+    for (int l = 0; l < 7; l++)
+      if (l == gl + G * c) f[c] = dvds[l];
+  }
+  // check_save at this state (once per output interval): equilibrium with the box test, residual, deriv_cold's
+  // dD/dw -- the base lane evaluates it with the cold kernels' fused routine, whose check outputs do not depend on
+  // the derivative model (rays_device.hpp: rhs_eval)
+  resid = 0.;
+  cs_flag = 0;
+  cs_stop = false;
+  if (any_check) {  // wave-uniform
+    double r_ = 0.;
+    int fl_ = 0, st_ = 0;
+    if (do_check && gl == GEO::kBaseLane) {
+      int code_u = 0;
+      bool stop_u = false;
+      double f_u[7];
+      rhs_eval<EQ, NS, RAYS_DERIV_COLD, 7>(P, v, true, r_, fl_, stop_u, code_u, f_u);
+      st_ = stop_u ? 1 : 0;
+    }
+    resid = grp_bcast<G>(r_, GEO::kBaseLane);
+    cs_flag = grp_bcast<G>(fl_, GEO::kBaseLane);
+    cs_stop = grp_bcast<G>(st_, GEO::kBaseLane) != 0;
+  }
+}
+
+#ifndef RAYS_HOST_EMUL
+template <int EQ, int NS, int G>
+__global__ void __launch_bounds__(256, 2)
+sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
+#else
+template <int EQ, int NS, int G>
+void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
+#endif
+{
+  typedef GrpGeom<G> GEO;
+  constexpr int C = GEO::CPL, NV = 7;
+  DevParams P;
+  hot_params<EQ, NS>(P_kernarg, P);
+  extern __shared__ double lds[];
+  const int gl = threadIdx.x & (G - 1);  // lane within the ray's group
+  const int gib = threadIdx.x / G;       // group within the block
+  GCoef S;
+  S.col = (sg_lds_ptr)(lds + gib);
+  S.stride = GEO::kRaysPerBlock;
+  GPhi<C> F;
+  F.clear();
+  bool valid[C];  // this lane's slot holds an ODE component
+#pragma unroll
+  for (int c = 0; c < C; c++) valid[c] = gl + G * c < NV;
+
+  const unsigned total_groups = gridDim.x * GEO::kRaysPerBlock;
+  const long long npt = (long long)P.nstep_max + 1;
+  constexpr double kEps = 2.220446049250313e-16;  // epsilon(1._rkind)
+  constexpr double twou = 2.0 * kEps, fouru = 2.0 * twou;
+  constexpr int maxnum = 500;  // ode_RAYS.f90:395
+
+  // ---- per-ray state, the same in every lane of the group unless marked (lane) --------------------------------------
+  int ray = blockIdx.x * GEO::kRaysPerBlock + gib;
+  bool alive = ray < A_hot.nray;
+  bool need_init = alive;
+  int pc = PC_CHECK;
+  int nstep = 0;
+  double sout = 0.;
+  double ds_ray = P.ds;
+  double last_resid = 0., prev_resid = 0., maxr = -1.7976931348623157e308;
+  double yy[C], pp[C], ysave[C];  // (lane) y of `step`, the predicted p, y of SG_ode (the state `ode` last returned)
+  Recip wt[C];                    // (lane)
+  double t = 0., tout = 0., x = 0., h = 0., hold = 0., eps = 0.;
+  double rel_err = 0., abs_err = 0., releps = 0., abseps = 0., absdel = 0., tend = 0.;
+  double p5eps = 0., round_ = 0., xold = 0., absh = 0., erk = 0., erkm1 = 0.;
+  int k = 1, kold = 0, ns = 0, knew = 1, ifail = 0, nostep = 0, kle4 = 0;
+  int resume = SEG_WAIT;
+  int waited = 0;
+  int patience = kSgPatienceMax, probe = 0;
+  unsigned fl = FL_START | FL_PHASE1 | FL_NORND | FL_FIRST;
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    yy[c] = pp[c] = ysave[c] = 0.;
+    wt[c] = make_recip(1.0);
+  }
+
+  while (__any(alive)) {
+    if (RAYS_RARE(need_init)) {  // ray_tracing.f90:77-93, SG_ode_m.f90:73-85
+      const TraceArgs& A = cold_args(A_hot);
+      double v0[NV];
+      start_ray<EQ, NS, NV>(P, A, ray, v0, sout, ds_ray);
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        yy[c] = 0.;
+#pragma unroll
+        for (int l = 0; l < NV; l++)
+          if (l == gl + G * c) yy[c] = v0[l];
+        ysave[c] = yy[c];
+      }
+      pc = PC_CHECK;
+      resume = SEG_WAIT;
+      fl |= FL_FIRST;
+      nstep = 0;
+      t = sout;
+      last_resid = 0.;
+      prev_resid = 0.;
+      maxr = -1.7976931348623157e308;
+      rel_err = P.rel_err0;
+      abs_err = P.abs_err0;
+      need_init = false;
+    }
+
+    // wave-uniform bound on the orders in play this trip (an order grows by at most one per trip)
+    int kcap = 2;
+#pragma unroll
+    for (int q = 2; q <= 12; q++) {
+      if (!__any(alive && k >= q)) break;
+      kcap = q + 1;
+    }
+    if (kcap > 12) kcap = 12;
+    const int rcap = kcap + 2;  // rows up to k + 2
+
+    // ---- which lanes does this trip's right-hand side serve (phase and interval alignment: rays_sg.hpp) -------------
+    const bool in_f2 = pc == PC_F2;
+    const bool wants_rhs = alive && resume == SEG_WAIT;
+    const bool at_check = pc == PC_CHECK;
+    bool act;
+    if (patience > 0) {
+      const int n_f2 = __popcll(__ballot(wants_rhs && in_f2));
+      const int n_f3 = __popcll(__ballot(wants_rhs && !in_f2 && !at_check));
+      const bool all_arrived = n_f2 + n_f3 == 0;
+      const bool timed_out = !all_arrived && __any(wants_rhs && at_check && waited >= patience);
+      const bool serve_check = all_arrived || timed_out;
+      const bool serve_f2 = n_f2 > n_f3;
+      act = wants_rhs && (serve_check ? at_check : (!at_check && in_f2 == serve_f2));
+      waited = (wants_rhs && at_check && !serve_check) ? waited + 1 : 0;
+      if (timed_out) patience = patience / 2;
+      else if (all_arrived) patience = patience + 8 < kSgPatienceMax ? patience + 8 : kSgPatienceMax;
+      probe = 0;
+    } else {
+      const int n_f2 = __popcll(__ballot(wants_rhs && in_f2)), n_other = __popcll(__ballot(wants_rhs && !in_f2));
+      const bool serve_f2 = n_f2 > n_other;
+      act = wants_rhs && (in_f2 == serve_f2);
+      waited = 0;
+      probe = probe + 1;
+      if (probe >= kSgProbeTrips) patience = kSgPatienceProbe;
+    }
+
+    // ---- the one right-hand side of this trip, spread over the group's lanes ---------------------------------------
+    double win[C], f[C], resid = 0.;
+    int code = 0, cs_flag = 0;
+    bool cs_stop = false;
+#pragma unroll
+    for (int c = 0; c < C; c++) win[c] = pc == PC_F2 ? pp[c] : yy[c];
+    const bool do_check = act && pc == PC_CHECK;
+    const bool any_check = __any(do_check);
+    group_rhs<EQ, NS, G>(P, win, gl, do_check, any_check, f, code, resid, cs_flag, cs_stop);
+
+    // ---- per-ray continuation (flat control flow, segments in pipeline order: rays_sg.hpp) -------------------------
+    int stop = 0;
+    int done = 0;
+    int seg = resume;
+    resume = SEG_WAIT;
+    int have_f = 0;
+    if (act) {
+      if (pc == PC_CHECK) {
+        seg = SEG_DE_BEGIN;
+        if (RAYS_RARE(fl & FL_FIRST)) {  // ray_tracing.f90:92-112
+          const TraceArgs& A = cold_args(A_hot);
+#pragma unroll
+          for (int c = 0; c < C; c++)
+            if (valid[c]) A.ray_vec[(long long)ray * npt * NV + gl + G * c] = yy[c];
+          if (gl == 0) A.residual[(long long)ray * npt] = 0.;
+          fl &= ~FL_FIRST;
+          if (RAYS_RARE(cs_stop)) {
+#pragma unroll
+            for (int c = 0; c < C; c++)
+              if (valid[c] && A.end_ray_vec) A.end_ray_vec[(long long)ray * NV + gl + G * c] = 0.;
+            if (gl == 0) {
+              A.npoints[ray] = 1;
+              A.stop_code[ray] = cs_flag;
+              if (A.end_residuals) A.end_residuals[ray] = 0.;
+              if (A.max_residuals) A.max_residuals[ray] = 0.;
+            }
+            done = 1;
+            stop = -1;
+            seg = SEG_WAIT;
+          }
+        } else {
+          if (RAYS_RARE(cs_stop)) {  // ray_tracing.f90:214-234
+            stop = cs_flag;
+            seg = SEG_STOP;
+          } else {  // :237-243
+            nstep = nstep + 1;
+            const TraceArgs& A = cold_args(A_hot);
+            const long long pt = (long long)ray * npt + nstep;
+#pragma unroll
+            for (int c = 0; c < C; c++)
+              if (valid[c]) A.ray_vec[pt * NV + gl + G * c] = yy[c];
+            if (gl == 0) A.residual[pt] = resid;
+            if (fabs(last_resid) > maxr) maxr = fabs(last_resid);
+            prev_resid = last_resid;
+            last_resid = resid;
+          }
+        }
+        if (seg == SEG_DE_BEGIN) {  // ray_tracing.f90:118-172
+          t = sout;
+          sout = sout + ds_ray;
+          tout = sout;
+          if (sout > P.s_max) {
+            stop = RAYS_STOP_SOUT_GT_SMAX;
+            seg = SEG_STOP;
+          } else if (nstep + 1 > P.nstep_max) {
+            stop = RAYS_STOP_NSTEP_MAX;
+            seg = SEG_STOP;
+          }
+          have_f = 1;
+        }
+      } else if (pc == PC_F1) {
+        have_f = 1;
+        seg = SEG_START_DONE;
+      } else if (pc == PC_F2) {
+        seg = SEG_AFTER_F2;
+      } else {
+        seg = SEG_AFTER_F3;
+      }
+    }
+
+    // ---- AFTER_F2: error estimates, accept or reject (ode_RAYS.f90:1020-1120) -------------------------------------
+    {
+      const bool here = seg == SEG_AFTER_F2 && !code;
+      if (RAYS_RARE(seg == SEG_AFTER_F2 && code)) {  // :1020
+        stop = code;
+        seg = SEG_STOP;
+      }
+      if (__any(here)) {  // wave-uniform
+        const int kp1 = k + 1, km1 = k - 1, km2 = k - 2;
+        double rk[C], rkm1[C], tm2[C], tm1[C], t0[C];
+        F.get(k, rk, rcap);
+        F.get(km1, rkm1, rcap);
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          const double ph1 = F.r[1][c];
+          const double q2 = div(rkm1[c] + f[c] - ph1, wt[c]);
+          const double q1 = div(rk[c] + f[c] - ph1, wt[c]);
+          const double q0 = div(f[c] - ph1, wt[c]);
+          tm2[c] = q2 * q2;
+          tm1[c] = q1 * q1;
+          t0[c] = q0 * q0;
+        }
+        const double s2 = grp_sum<G>(tm2), s1 = grp_sum<G>(tm1), s0 = grp_sum<G>(t0);
+        if (here) {
+          double erkm2 = 0.0;
+          erkm1 = 0.0;
+          if (0 < km2) erkm2 = absh * S.sig(km1) * gstr(km2) * sqrt(s2);
+          if (0 <= km2) erkm1 = absh * S.sig(k) * gstr(km1) * sqrt(s1);
+          const double err = absh * sqrt(s0) * (S.g(k) - S.g(kp1));
+          erk = absh * sqrt(s0) * S.sig(kp1) * gstr(k);
+          knew = k;
+          if (0 < km2) {
+            if (fmax(erkm1, erkm2) <= erk) knew = km1;
+          } else if (0 == km2) {
+            if (erkm1 <= 0.5 * erk) knew = km1;
+          }
+          if (err <= eps) {
+            // ---- successful: correct (:1128-1142) ----
+            kold = k;
+            hold = h;
+            const double hg = h * S.g(kp1);
+            if (!(fl & FL_NORND)) {
+#pragma unroll
+              for (int c = 0; c < C; c++) {
+                const double rho = hg * (f[c] - F.r[1][c]) - F.r[16][c];
+                yy[c] = pp[c] + rho;
+                F.r[15][c] = (yy[c] - pp[c]) - rho;
+              }
+            } else {
+#pragma unroll
+              for (int c = 0; c < C; c++) yy[c] = pp[c] + hg * (f[c] - F.r[1][c]);
+            }
+            pc = PC_F3;
+            seg = SEG_WAIT;
+          } else {
+            // ---- failed step: restore, shrink (:1086-1120) ----
+            fl &= ~FL_PHASE1;
+            x = xold;
+            F.restore(k, S, kcap);
+            for (int i = 2; i <= k; i++) S.psi(i - 1) = S.psi(i) - h;
+            ifail = ifail + 1;
+            double temp2 = 0.5;
+            if (3 < ifail) {
+              if (p5eps < 0.25 * erk) temp2 = sqrt(p5eps / erk);
+            }
+            if (3 <= ifail) knew = 1;
+            h = temp2 * h;
+            k = knew;
+            if (fabs(h) < fouru * fabs(x)) {
+              h = copysign(fouru * fabs(x), h);
+              eps = eps + eps;
+              seg = SEG_CRASH;
+            } else {
+              seg = SEG_COEF;
+            }
+          }
+        }
+      }
+    }
+
+    // ---- AFTER_F3: update differences, choose order and step size (:1145-1231) ---------------------------------------
+    {
+      const bool here = seg == SEG_AFTER_F3 && !code;
+      if (RAYS_RARE(seg == SEG_AFTER_F3 && code)) {  // :1145
+        stop = code;
+        seg = SEG_STOP;
+      }
+      if (__any(here)) {  // wave-uniform
+        const int kp1 = k + 1, kp2 = k + 2, km1 = k - 1;
+        double d1[C], d2[C], tp[C];
+        F.get(kp2, d2, rcap);
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          d1[c] = f[c] - F.r[1][c];
+          d2[c] = d1[c] - d2[c];
+          const double q = div(d2[c], wt[c]);
+          tp[c] = q * q;
+        }
+        const double sp = grp_sum<G>(tp);
+        if (here) {
+          F.set(kp1, d1, rcap);
+          F.set(kp2, d2, rcap);
+          F.add(k, d1, kcap);
+          double erkp1 = 0.0;
+          if (knew == km1 || k == 12) fl &= ~FL_PHASE1;
+          if (fl & FL_PHASE1) {
+            k = kp1;
+            erk = erkp1;
+          } else if (knew == km1) {
+            k = km1;
+            erk = erkm1;
+          } else if (kp1 <= ns) {
+            erkp1 = absh * gstr(kp1) * sqrt(sp);
+            if (k == 1) {
+              if (erkp1 < 0.5 * erk) {
+                k = kp1;
+                erk = erkp1;
+              }
+            } else if (erkm1 <= fmin(erk, erkp1)) {
+              k = km1;
+              erk = erkm1;
+            } else if (erkp1 < erk && k < 12) {
+              k = kp1;
+              erk = erkp1;
+            }
+          }
+          double hnew = h + h;
+          if (!(fl & FL_PHASE1)) {
+            const double two_k1 = (double)(2 << k);  // two(k+1)
+            if (p5eps < erk * two_k1) {
+              hnew = h;
+              if (p5eps < erk) {
+                const double temp2 = (double)(k + 1);
+                const double r = libm::pow(p5eps / erk, 1.0 / temp2);
+                hnew = absh * fmax(0.5, fmin((double)0.9f, r));
+                hnew = copysign(fmax(hnew, fouru * fabs(x)), h);
+              }
+            }
+          }
+          h = hnew;
+          // ---- back in de (:579-588) ----
+          nostep = nostep + 1;
+          kle4 = kle4 + 1;
+          if (4 < kold) kle4 = 0;
+          if (50 <= kle4) fl |= FL_STIFF;
+          seg = SEG_DE_TOP;
+        }
+      }
+    }
+
+    if (RAYS_RARE(seg == SEG_CRASH)) {  // de returns iflag = 3 (:566-575), SG_ode_m.f90:139-149
+      rel_err = eps * releps;
+      abs_err = eps * abseps;
+#pragma unroll
+      for (int c = 0; c < C; c++) ysave[c] = yy[c];  // y = yy
+      t = x;
+      const double total_error = fabs(rel_err) + fabs(abs_err);
+      if (total_error > P.sg_error_limit) {
+        stop = RAYS_STOP_ODE_TOTAL_ERROR;
+        seg = SEG_STOP;
+      } else {
+        have_f = 0;
+        seg = SEG_DE_BEGIN;
+      }
+    }
+
+    if (seg == SEG_DE_BEGIN) {  // de parameter tests + restart (:423-505)
+      if (t == tout) {
+        stop = RAYS_STOP_SG_T_EQ_TOUT;
+        seg = SEG_STOP;
+      } else if (rel_err < 0.0 || abs_err < 0.0) {
+        stop = RAYS_STOP_SG_NEG_ERR;
+        seg = SEG_STOP;
+      } else {
+        eps = fmax(rel_err, abs_err);
+        if (eps <= 0.0) {
+          stop = RAYS_STOP_SG_EPS_LE_0;
+          seg = SEG_STOP;
+        } else {
+          const double del = tout - t;
+          absdel = fabs(del);
+          tend = t + 10.0 * del;  // :485
+          nostep = 0;
+          kle4 = 0;
+          fl &= ~FL_STIFF;
+          releps = rel_err / eps;
+          abseps = abs_err / eps;
+          fl |= FL_START;  // :497-505
+          x = t;
+          h = copysign(fmax(fabs(tout - x), fouru * fabs(x)), tout - x);
+          seg = SEG_DE_TOP;
+        }
+      }
+    }
+
+    // ---- DE_TOP: interval complete (intrp), or the entry of `step` (:511-556, 833-885) ------------------------------
+    {
+      const bool top = seg == SEG_DE_TOP;
+      const bool finish = top && absdel <= fabs(x - t);
+      const bool enter = top && !finish && !(maxnum <= nostep);
+      if (RAYS_RARE(top && !finish && maxnum <= nostep)) {  // :536-548
+        stop = (fl & FL_STIFF) ? RAYS_STOP_SG_STIFF : RAYS_STOP_SG_MAXNUM;
+#pragma unroll
+        for (int c = 0; c < C; c++) ysave[c] = yy[c];
+        t = x;
+        seg = SEG_STOP;
+      }
+      if (finish) {
+        // ---- intrp (:1235-1362) -> y(tout) ----
+        const double hi = tout - x;
+        const int ki = kold + 1;
+        for (int i = 1; i <= ki; i++) S.wi(i) = 1.0 / (double)i;
+        S.gi(1) = 1.0;
+        double term = 0.0;
+        for (int j = 2; j <= ki; j++) {
+          const double psijm1 = S.psi(j - 1);
+          const Recip rpsi = make_recip(psijm1);
+          const double gamma = div(hi + term, rpsi);
+          const double eta = div(hi, rpsi);
+          for (int i = 1; i <= ki + 1 - j; i++) S.wi(i) = gamma * S.wi(i) - eta * S.wi(i + 1);
+          S.gi(j) = S.wi(1);
+          term = psijm1;
+        }
+        double yout[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) yout[c] = 0.0;
+        F.interp(ki, S, yout, kcap + 1);
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          yy[c] = yy[c] + hi * yout[c];
+          ysave[c] = yy[c];
+        }
+        t = tout;
+        pc = PC_CHECK;
+        seg = SEG_WAIT;
+      }
+      if (__any(enter)) {  // wave-uniform
+        double tq[C];
+        if (enter) {
+          h = copysign(fmin(fabs(h), fabs(tend - x)), h);  // :552-553
+#pragma unroll
+          for (int c = 0; c < C; c++) wt[c] = make_recip(releps * fabs(yy[c]) + abseps);
+        }
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          const double q = div(yy[c], wt[c]);
+          tq[c] = q * q;
+        }
+        const double sm = grp_sum<G>(tq);
+        if (enter) {
+          if (fabs(h) < fouru * fabs(x)) {
+            h = copysign(fouru * fabs(x), h);
+            seg = SEG_CRASH;
+          } else {
+            p5eps = 0.5 * eps;
+            round_ = twou * sqrt(sm);  // :844
+            if (p5eps < round_) {
+              eps = 2.0 * round_ * (1.0 + fouru);
+              seg = SEG_CRASH;
+            } else {
+              S.g(1) = 1.0;
+              S.g(2) = 0.5;
+              S.sig(1) = 1.0;
+              if (fl & FL_START) {
+                if (have_f) {
+                  seg = SEG_START_DONE;
+                } else {  // f(x, yy) needed (:860)
+                  pc = PC_F1;
+                  seg = SEG_WAIT;
+                }
+              } else {
+                ifail = 0;
+                seg = SEG_COEF;
+              }
+            }
+          }
+        }
+      }
+    }
+
+    // ---- START_DONE: first step of an interval (:863-885) ------------------------------------------------------------
+    {
+      const bool here = seg == SEG_START_DONE && !code;
+      if (RAYS_RARE(seg == SEG_START_DONE && code)) {  // :863
+        stop = code;
+        seg = SEG_STOP;
+      }
+      if (__any(here)) {  // wave-uniform
+        double tq[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          const double q = div(f[c], wt[c]);
+          tq[c] = q * q;
+        }
+        const double sm = grp_sum<G>(tq);
+        if (here) {
+          have_f = 0;
+#pragma unroll
+          for (int c = 0; c < C; c++) {
+            F.r[1][c] = f[c];
+            F.r[2][c] = 0.0;
+          }
+          const double total = sqrt(sm);
+          absh = fabs(h);
+          if (eps < 16.0 * total * h * h) absh = 0.25 * sqrt(eps / total);
+          h = copysign(fmax(absh, fouru * fabs(x)), h);
+          hold = 0.0;
+          k = 1;
+          kold = 0;
+          fl &= ~FL_START;
+          fl |= FL_PHASE1;
+          fl |= FL_NORND;
+          if (p5eps <= 100.0 * round_) {
+            fl &= ~FL_NORND;
+#pragma unroll
+            for (int c = 0; c < C; c++) F.r[15][c] = 0.0;
+          }
+          ifail = 0;
+          seg = SEG_COEF;
+        }
+      }
+    }
+
+    // ---- COEF: coefficients + predictor (:892-1015) ------------------------------------------------------------------
+    if (seg == SEG_COEF) {
+      const int kp1 = k + 1, kp2 = k + 2;
+      if (h != hold) ns = 0;
+      if (ns <= kold) ns = ns + 1;
+      const int nsp1 = ns + 1;
+      if (ns <= k) {
+        S.beta(ns) = 1.0;
+        S.alpha(ns) = 1.0 / (double)ns;
+        double temp1 = h * (double)ns;
+        S.sig(nsp1) = 1.0;
+        for (int i = nsp1; i <= k; i++) {
+          const double temp2 = S.psi(i - 1);
+          S.psi(i - 1) = temp1;
+          S.beta(i) = S.beta(i - 1) * S.psi(i - 1) / temp2;
+          temp1 = temp2 + h;
+          S.alpha(i) = h / temp1;
+          S.sig(i + 1) = (double)i * S.alpha(i) * S.sig(i);
+        }
+        S.psi(k) = temp1;
+        double w[14];
+#pragma unroll
+        for (int iq = 0; iq < 14; iq++) w[iq] = 0.;
+        if (ns <= 1) {
+#pragma unroll
+          for (int iq = 1; iq <= 12; iq++) {
+            if (iq > kcap) break;
+            if (iq <= k) {
+              const double cq = 1.0 / (double)(iq * (iq + 1));
+              S.v(iq) = cq;
+              w[iq] = cq;
+            }
+          }
+        } else {
+          if (kold < k) {
+            S.v(k) = 1.0 / (double)(k * kp1);
+            for (int j = 1; j <= ns - 2; j++) {
+              const int i = k - j;
+              S.v(i) = S.v(i) - S.alpha(j + 1) * S.v(i + 1);
+            }
+          }
+          const double a_ns = S.alpha(ns);
+          const int lim = kp1 - ns;
+#pragma unroll
+          for (int iq = 1; iq <= 12; iq++) {  // ascending: v(iq+1) is still the old value
+            if (iq > kcap) break;
+            if (iq <= lim) {
+              const double cq = S.v(iq) - a_ns * S.v(iq + 1);
+              S.v(iq) = cq;
+              w[iq] = cq;
+            }
+          }
+          S.g(nsp1) = w[1];
+        }
+        for (int i = ns + 2; i <= kp1; i++) {
+          const double a = S.alpha(i - 1);
+          const int lim = kp2 - i;
+#pragma unroll
+          for (int iq = 1; iq <= 12; iq++) {
+            if (iq > kcap) break;
+            if (iq <= lim) w[iq] = w[iq] - a * w[iq + 1];
+          }
+          S.g(i) = w[1];
+        }
+      }
+      F.scale(nsp1, k, S, kcap);
+      {
+        double row[C];
+        F.get(kp1, row, rcap);
+        F.set(kp2, row, rcap);  // phi(:,kp2) = phi(:,kp1)
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          row[c] = 0.0;
+          pp[c] = 0.0;
+        }
+        F.set(kp1, row, rcap);  // phi(:,kp1) = 0
+      }
+      F.predict(k, S, pp, kcap);
+      if (!(fl & FL_NORND)) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          const double tau = h * pp[c] - F.r[15][c];
+          pp[c] = yy[c] + tau;
+          F.r[16][c] = (pp[c] - yy[c]) - tau;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; c++) pp[c] = yy[c] + h * pp[c];
+      }
+      xold = x;
+      x = x + h;
+      absh = fabs(h);
+      pc = PC_F2;
+      seg = SEG_WAIT;
+    }
+
+    if (RAYS_RARE(seg == SEG_STOP)) {
+      done = 1;
+      seg = SEG_WAIT;
+    }
+    if (RAYS_RARE(seg != SEG_WAIT)) resume = seg;  // SEG_CRASH entered from DE_TOP: next trip
+
+    if (RAYS_RARE(done && stop >= 0)) {  // ray_tracing.f90:252-260
+      const TraceArgs& A = cold_args(A_hot);
+      if (A.end_ray_vec) {
+#pragma unroll
+        for (int c = 0; c < C; c++)
+          if (valid[c]) A.end_ray_vec[(long long)ray * NV + gl + G * c] = ysave[c];
+      }
+      if (gl == 0) {
+        A.npoints[ray] = nstep + 1;
+        A.stop_code[ray] = stop;
+        if (A.end_residuals) A.end_residuals[ray] = nstep >= 1 ? prev_resid : 0.;
+        if (A.max_residuals) A.max_residuals[ray] = maxr;
+      }
+    }
+
+    // ---- refill finished groups --------------------------------------------------------------------------------------
+    if (__any(done)) {  // wave-uniform
+      int nxt = 0;
+      if (done && gl == 0) nxt = (int)(atomicAdd(cold_args(A_hot).next_ray, 1u) + total_groups);
+      nxt = grp_bcast<G>(nxt, 0);
+      if (done) {
+        if ((unsigned)nxt < (unsigned)A_hot.nray) {
+          ray = nxt;
+          need_init = true;
+        } else {
+          alive = false;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace rays

@@ -23,8 +23,12 @@ extern thread_local emul_dim3 threadIdx, blockIdx, blockDim, gridDim;
   thread_local emul_dim3 threadIdx, blockIdx, blockDim, gridDim; \
   namespace rays { thread_local double lds[1 << 16]; }
 
+#ifdef RAYS_EMUL_WAVE
+#include "hip_wave_emul.h"   // 64 lanes per wave as fibers: __any / __ballot / __shfl are real cross-lane operations
+#else
 inline int __any(int x) { return x; }
 inline unsigned long long __ballot(int x) { return x ? 1ull : 0ull; }
+#endif
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 #define __builtin_amdgcn_readlane(v, r) ((r) == 0 ? (v) : 0)  /* only lane 0 exists */
 #define __builtin_amdgcn_wave_barrier() ((void)0)

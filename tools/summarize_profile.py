@@ -11,17 +11,20 @@ import sys
 out, args = sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else ""
 agg = collections.defaultdict(list)
 kernel = None
+bench = json.loads(open(os.path.join(out, "bench.json")).read().strip().splitlines()[-1])
+# the kernel of the bench line (the run also times the other numerics flavour of the same kernel: not this one's counters)
+want = "rays::" + bench["config"]["kernel"]
+is_it = lambda name: name.split("(")[0].replace("void ", "").strip() == want
 for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "trace_kernel" in r["Kernel_Name"]:
+        if is_it(r["Kernel_Name"]):
             kernel = r["Kernel_Name"].split("(")[0].replace("void ", "")
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 c = {k: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for k, v in sorted(agg.items())}
 m = lambda k: c[k]["mean_per_launch"] if k in c else None
-bench = json.loads(open(os.path.join(out, "bench.json")).read().strip().splitlines()[-1])
 stats = {}
 for r in csv.DictReader(open(os.path.join(out, "kernel_stats.csv"))):
-    if "trace_kernel" in r["Name"]:
+    if is_it(r["Name"]):
         stats = {"name": r["Name"].split("(")[0], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                  "percentage": float(r["Percentage"])}
 d = {}
@@ -43,7 +46,10 @@ if m("SQ_WAVE_CYCLES") and m("SQ_WAIT_ANY"):
     d["wave_time_parked_in_waitcnt"] = m("SQ_WAIT_ANY") / m("SQ_WAVE_CYCLES")
 if m("GRBM_GUI_ACTIVE") and stats:
     d["effective_clock_GHz"] = m("GRBM_GUI_ACTIVE") / 8.0 / stats["avg_ns"]  # summed over 8 XCDs
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402
 summary = {"command": f"tools/profile_bench.sh ... {args}".strip(), "kernel": kernel, "kernel_stats": stats,
+           "source_hash": kernel_source_hash(),
            "bench_line": bench, "counters": c, "derived": d,
            "note": "WRITE_SIZE/FETCH_SIZE are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half)"}
 json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)

@@ -7,14 +7,18 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_source_hash  # noqa: E402
 path = os.path.join(ROOT, "profiles", "counters.json")
 db = json.load(open(path)) if os.path.exists(path) else {}
 for f in sys.argv[1:]:
     s = json.load(open(f))
     c, d, b = s["counters"], s["derived"], s["bench_line"]
     m = lambda k: c[k]["mean_per_launch"] if k in c else None
-    db[b["config"]["workload"]] = {
-        "kernel": b["config"]["kernel"], "hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"),
+    # keyed by workload AND kernel (a workload has an exact and a tolerance flavour); source_hash = the kernel sources
+    # the counters were collected from (written by summarize_profile.py on the GPU box, i.e. from the snapshot that ran)
+    db[b["config"]["workload"] + "::" + b["config"]["kernel"]] = {
+        "kernel": b["config"]["kernel"], "source_hash": s.get("source_hash") or kernel_source_hash(), "hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"),
         "fp64_wave_insts": {k: m(f"SQ_INSTS_VALU_{k.upper()}_F64") for k in ("add", "mul", "fma", "trans")
                             if m(f"SQ_INSTS_VALU_{k.upper()}_F64") is not None},
         "valu_insts": m("SQ_INSTS_VALU"), "effective_clock_GHz": d.get("effective_clock_GHz"),
