@@ -106,6 +106,7 @@
     end type rays_device_result_t
 
     integer(c_int), parameter :: RAYS_TRACE_NO_ZERO_FILL = 1
+    integer(c_int), parameter :: RAYS_NUMERICS_EXACT = 0, RAYS_NUMERICS_TOLERANCE = 1
     integer(c_int), parameter :: RAYS_DEP_PTOTAL_PSI = 0, RAYS_DEP_PTOTAL_RHO = 1, RAYS_DEP_PTOTAL_X = 2
 
     interface
@@ -125,6 +126,17 @@
        integer(c_int) function rays_hip_finalize() bind(C, name='rays_hip_finalize')
           import :: c_int
        end function rays_hip_finalize
+
+       ! numerics of the trace kernels: RAYS_NUMERICS_EXACT (0, default: bit-identical to the CPU path) or
+       ! RAYS_NUMERICS_TOLERANCE (1: every step within 1e-10 relative, counts and stop flags exact; cold RK4 kernels)
+       integer(c_int) function rays_hip_set_numerics(mode) bind(C, name='rays_hip_set_numerics')
+          import :: c_int
+          integer(c_int), value :: mode
+       end function rays_hip_set_numerics
+
+       integer(c_int) function rays_hip_get_numerics() bind(C, name='rays_hip_get_numerics')
+          import :: c_int
+       end function rays_hip_get_numerics
 
        integer(c_int) function rays_hip_last_error(buf, len) bind(C, name='rays_hip_last_error')
           import :: c_int, c_char

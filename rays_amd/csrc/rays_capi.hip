@@ -156,9 +156,18 @@ const rays::KernelEntry* find_kernel(const rays_params_t& p, long long nray = 0)
   bool big = nray >= 2ll * ncu * 256;  // >= two waves per SIMD
   if (const char* f = std::getenv("RAYS_HIP_FORCE_WAVES_PER_SIMD"))  // developer measurement: "1" | "2"
     big = f[0] == '2';
+  // SG with finite-difference dD (nv = 7) exists in two mappings: one ray per group of four lanes
+  // (rays_sg_group.hpp, the default: 212 against 300 ms per pass on the 64k-ray Solovev fan) and one ray per lane
+  // (rays_sg.hpp; RAYS_HIP_SG_GROUP=0, for A/B measurements).  Both are bit-identical to the reference.
+  bool group = true;
+  if (const char* f = std::getenv("RAYS_HIP_SG_GROUP")) group = f[0] != '0';
   const KernelEntry* found = nullptr;
   for (int i = 0; i < n; i++)
     if (e[i].ns == p.nspec + 1 && e[i].nv == p.nv) {
+      if (e[i].lanes_per_ray > 1) {
+        if (group) return &e[i];
+        continue;
+      }
       if (e[i].occ == 1 && !found) found = &e[i];
       if (e[i].occ == 2 && big) return &e[i];
     }
@@ -589,9 +598,12 @@ int launch_trace(const rays_params_t* p, int nray, const double* d_rvec0, const 
   if (kernel->sg_far_per_lane > 0) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    // the SG kernels fill the CU's LDS with one workgroup, so at most one 256-lane block per CU is resident
-    const long long resident = (long long)rays::device_cu_count(dev) * rays::kBlock;
-    const long long want = ((long long)nray + rays::kBlock - 1) / rays::kBlock * rays::kBlock;
+    // the one-ray-per-lane SG kernels fill the CU's LDS with one workgroup, so at most one 256-lane block per CU is
+    // resident; the lane-group kernels (G lanes per ray) hold up to four
+    const int G = kernel->lanes_per_ray;
+    const long long resident = (long long)rays::device_cu_count(dev) * rays::kBlock * (G > 1 ? 4 : 1);
+    const long long rays_per_block = rays::kBlock / G;
+    const long long want = ((long long)nray + rays_per_block - 1) / rays_per_block * rays::kBlock;
     A.sg_far_lanes = want < resident ? want : resident;
     double* ws = nullptr;
     rc = get_sg_workspace(stream, sizeof(double) * (size_t)kernel->sg_far_per_lane * (size_t)A.sg_far_lanes, &ws);

@@ -271,6 +271,7 @@ struct EqPoint {
   double bvec[3], bmag, gradbmag[3], bunit[3], gradbunit[3][3], gbt[3][3];
   double ns[NS], gradns[NS][3], ts0, gradts0[3];
   double alpha[NS], gamma[NS];
+  double omgc[NS], omgp2[NS];  // cyclotron frequencies (signed) and plasma frequencies squared: deriv_num's omega differences
   double omgc0;  // electron cyclotron frequency (signed), for damp_fund_ECH
   Recip rbmag;   // shared reciprocal of |B|
   int err;
@@ -876,6 +877,8 @@ RAYS_DEV void equilibrium(const DevParams& P, const Recip& Romgrf, const Recip& 
     const double omgp2 = div(ns[is] * P.qs2[is], const_recip(P.eps0ms[is], P.inv_eps0ms[is]));
     eq.alpha[is] = div(omgp2, Romgrf2);
     eq.gamma[is] = div(omgc, Romgrf);
+    eq.omgc[is] = omgc;
+    eq.omgp2[is] = omgp2;
     if (is == 0) eq.omgc0 = omgc;
   }
   eq.ts0 = ts[0];
@@ -1044,21 +1047,34 @@ RAYS_DEV double epsn_det(double e11, double e33, double x12, double n1, double n
   return E33 * (E11 * E22 - x12 * x12) - E13 * (E22 * E13);
 }
 
-// determ                    deriv_num.f90:99-153 (ray_dispersion_model == 'cold')
+// determ                    deriv_num.f90:99-153 (ray_dispersion_model == 'cold'), in two parts: what depends on the
+// plasma parameters alone (the dielectric tensor and the product of :146) and what depends on the wave vector.
+// deriv_num's six wave-vector differences share the first part (same alpha, gamma: same bits).
+struct DetermEps {
+  double e11, e33, x12, pr;
+};
 template <int NS>
-RAYS_DEV double determ(const double bunit[3], const double alpha[NS], const double gamma[NS],
-                       const double kvec[3], const Recip& Rk0) {
+RAYS_DEV DetermEps determ_eps(const double alpha[NS], const double gamma[NS]) {
+  DetermEps E;
+  eps_cold<NS>(alpha, gamma, E.e11, E.e33, E.x12);
+  double pr = 1.;
+#pragma unroll
+  for (int is = 0; is < NS; is++) pr *= (1. - sq(gamma[is]));  // :146 (unused species contribute 1)
+  E.pr = pr;
+  return E;
+}
+RAYS_DEV double determ_k(const double bunit[3], const DetermEps& E, const double kvec[3], const Recip& Rk0) {
   const double k3 = kvec[0] * bunit[0] + kvec[1] * bunit[1] + kvec[2] * bunit[2];
   const double k1 = fsqrt(sq(kvec[0] - k3 * bunit[0]) + sq(kvec[1] - k3 * bunit[1]) + sq(kvec[2] - k3 * bunit[2]));
   const double n1 = div(k1, Rk0), n3 = div(k3, Rk0);
   const double nsq = sq(n1) + 0. + sq(n3);
-  double e11, e33, x12;
-  eps_cold<NS>(alpha, gamma, e11, e33, x12);
-  const double det = epsn_det(e11, e33, x12, n1, n3, nsq);
-  double pr = 1.;
-#pragma unroll
-  for (int is = 0; is < NS; is++) pr *= (1. - sq(gamma[is]));  // :146 (unused species contribute 1)
-  return det * pr;
+  const double det = epsn_det(E.e11, E.e33, E.x12, n1, n3, nsq);
+  return det * E.pr;
+}
+template <int NS>
+RAYS_DEV double determ(const double bunit[3], const double alpha[NS], const double gamma[NS],
+                       const double kvec[3], const Recip& Rk0) {
+  return determ_k(bunit, determ_eps<NS>(alpha, gamma), kvec, Rk0);
 }
 
 // Light equilibrium for determ: only bunit, alpha, gamma at a (possibly perturbed) point.
@@ -1103,6 +1119,7 @@ RAYS_DEV void deriv_num(const DevParams& P, const EqPoint<NS>& eq0, const double
     if (i == 1) dddx[1] = d;
     if (i == 2) dddx[2] = d;
   }
+  const DetermEps E0 = determ_eps<NS>(eq0.alpha, eq0.gamma);  // the same tensor in all six wave-vector differences
 #pragma unroll 1
   for (int i = 0; i < 3; i++) {  // :60-68
     const double ki = (i == 0) ? kvec0[0] : (i == 1) ? kvec0[1] : kvec0[2];
@@ -1113,20 +1130,30 @@ RAYS_DEV void deriv_num(const DevParams& P, const EqPoint<NS>& eq0, const double
       kp[c] = (c == i) ? kvec0[c] + change : kvec0[c];
       km[c] = (c == i) ? kvec0[c] - change : kvec0[c];
     }
-    const double det_plus = determ<NS>(eq0.bunit, eq0.alpha, eq0.gamma, kp, Rk0);
-    const double det_minus = determ<NS>(eq0.bunit, eq0.alpha, eq0.gamma, km, Rk0);
+    const double det_plus = determ_k(eq0.bunit, E0, kp, Rk0);
+    const double det_minus = determ_k(eq0.bunit, E0, km, Rk0);
     const double d = (det_plus - det_minus) / (2. * change);
     if (i == 0) dddk[0] = d;
     if (i == 1) dddk[1] = d;
     if (i == 2) dddk[2] = d;
   }
-  // :71-80 omega: per-lane omgrf/k0 instead of rewriting module variables
-  eq_for_determ<EQ, NS>(P, const_recip(P.omgrf_p, P.inv_omgrf_p), const_recip(P.omgrf2_p, P.inv_omgrf2_p),
-                        rvec0, bu, al, ga);
-  const double det_plus = determ<NS>(bu, al, ga, kvec0, const_recip(P.k0_p, P.inv_k0_p));
-  eq_for_determ<EQ, NS>(P, const_recip(P.omgrf_m, P.inv_omgrf_m), const_recip(P.omgrf2_m, P.inv_omgrf2_m),
-                        rvec0, bu, al, ga);
-  const double det_minus = determ<NS>(bu, al, ga, kvec0, const_recip(P.k0_m, P.inv_k0_m));
+  // :71-80 omega: per-lane omgrf/k0 instead of rewriting module variables.  The equilibrium at the same point with
+  // another omgrf has the same fields; only alpha = omgp2 / omgrf**2 and gamma = omgc / omgrf change
+  // (equilibrium_m.f90:262-265): the same two quotients from the unperturbed point's omgp2, omgc -- same bits,
+  // without evaluating the fields twice more.
+  (void)bu;
+#pragma unroll
+  for (int is = 0; is < NS; is++) {
+    al[is] = div(eq0.omgp2[is], const_recip(P.omgrf2_p, P.inv_omgrf2_p));
+    ga[is] = div(eq0.omgc[is], const_recip(P.omgrf_p, P.inv_omgrf_p));
+  }
+  const double det_plus = determ<NS>(eq0.bunit, al, ga, kvec0, const_recip(P.k0_p, P.inv_k0_p));
+#pragma unroll
+  for (int is = 0; is < NS; is++) {
+    al[is] = div(eq0.omgp2[is], const_recip(P.omgrf2_m, P.inv_omgrf2_m));
+    ga[is] = div(eq0.omgc[is], const_recip(P.omgrf_m, P.inv_omgrf_m));
+  }
+  const double det_minus = determ<NS>(eq0.bunit, al, ga, kvec0, const_recip(P.k0_m, P.inv_k0_m));
   dddw = (det_plus - det_minus) / P.omgrf0_delta;
 }
 

@@ -12,6 +12,10 @@
 #include "rays_rk4.hpp"
 #else
 #include "rays_sg.hpp"
+#if RAYS_INST_DERIV == 1 && !RAYS_INST_MS
+#include "rays_sg_group.hpp"   // finite-difference dD, nv = 7: one ray per group of lanes
+#define RAYS_INST_GROUP 1
+#endif
 #endif
 
 #ifndef RAYS_INST_MS
@@ -67,6 +71,20 @@ hipError_t launch_one(const DevParams& P, const TraceArgs& A, hipStream_t stream
 #endif
 }
 
+#ifdef RAYS_INST_GROUP
+#ifndef RAYS_SG_GROUP_LANES
+#define RAYS_SG_GROUP_LANES 4
+#endif
+template <int NS>
+hipError_t launch_group(const DevParams& P, const TraceArgs& A, hipStream_t stream, int* grid_blocks) {
+  typedef GrpGeom<RAYS_SG_GROUP_LANES> GEO;
+  static_assert(GEO::kThreads == kBlock, "the lane-group kernel is written for the launch block size");
+  return launch_persistent(sg_group_kernel<EQ, NS, RAYS_SG_GROUP_LANES>, GEO::kLdsBytes, P, A, stream, grid_blocks,
+                           GEO::kRaysPerBlock);
+}
+#define RAYS_ENTRY_GROUP(NS) \
+  { RAYS_INST_SOLVER, EQ, NS, DERIV, 7, 1, sg_group_far_doubles_per_lane<RAYS_SG_GROUP_LANES>(), RAYS_SG_GROUP_LANES, "sg_group_kernel<" RAYS_STR(RAYS_INST_EQT) ", " #NS ", " RAYS_STR(RAYS_SG_GROUP_LANES) ">", &launch_group<NS> }
+#endif
 #if RAYS_INST_SOLVER == 0
 #define RAYS_KNAME "rk4_trace_kernel"
 #else
@@ -78,10 +96,10 @@ hipError_t launch_one(const DevParams& P, const TraceArgs& A, hipStream_t stream
 #define RAYS_SG_FAR(NV) sg_far_doubles_per_lane<NV>()
 #endif
 #define RAYS_ENTRY(NS, NV) \
-  { RAYS_INST_SOLVER, EQ, NS, DERIV, NV, 1, RAYS_SG_FAR(NV), RAYS_KNAME "<" RAYS_STR(RAYS_INST_EQT) ", " #NS ", " RAYS_STR(RAYS_INST_DERIV) ", " #NV ">", &launch_one<NS, NV> }
+  { RAYS_INST_SOLVER, EQ, NS, DERIV, NV, 1, RAYS_SG_FAR(NV), 1, RAYS_KNAME "<" RAYS_STR(RAYS_INST_EQT) ", " #NS ", " RAYS_STR(RAYS_INST_DERIV) ", " #NV ">", &launch_one<NS, NV> }
 // two-waves-per-SIMD build of an RK4 kernel (large fans; rays_rk4.hpp)
 #define RAYS_ENTRY_OCC2(NS, NV) \
-  { RAYS_INST_SOLVER, EQ, NS, DERIV, NV, 2, 0, "rk4_trace_kernel_w2<" RAYS_STR(RAYS_INST_EQT) ", " #NS ", " RAYS_STR(RAYS_INST_DERIV) ", " #NV ">", &launch_one<NS, NV, 2> }
+  { RAYS_INST_SOLVER, EQ, NS, DERIV, NV, 2, 0, 1, "rk4_trace_kernel_w2<" RAYS_STR(RAYS_INST_EQT) ", " #NS ", " RAYS_STR(RAYS_INST_DERIV) ", " #NV ">", &launch_one<NS, NV, 2> }
 
 const KernelEntry kEntries[] = {
 #if RAYS_INST_MS
@@ -94,6 +112,9 @@ const KernelEntry kEntries[] = {
 #endif
 #elif defined(RAYS_INST_FAST)  // developer builds (make FAST=1): electrons + one ion species only
     RAYS_ENTRY(2, 7), RAYS_ENTRY(2, 8),
+#ifdef RAYS_INST_GROUP
+    RAYS_ENTRY_GROUP(2),
+#endif
 #if RAYS_INST_SOLVER == 0 && RAYS_INST_EQ != 2 && !defined(RAYS_HOST_EMUL)
     RAYS_ENTRY_OCC2(2, 7),
 #endif
@@ -103,6 +124,10 @@ const KernelEntry kEntries[] = {
     // nv = 8 | 13: + total-absorption row (damping_model = 'damp_fund_ECH', ode_m.f90:162-166)
     RAYS_ENTRY(1, 8), RAYS_ENTRY(2, 8), RAYS_ENTRY(3, 8), RAYS_ENTRY(4, 8), RAYS_ENTRY(5, 8), RAYS_ENTRY(6, 8),
     RAYS_ENTRY(1, 13), RAYS_ENTRY(2, 13), RAYS_ENTRY(3, 13), RAYS_ENTRY(4, 13), RAYS_ENTRY(5, 13), RAYS_ENTRY(6, 13),
+#ifdef RAYS_INST_GROUP
+    // SG + finite-difference dD, nv = 7: one ray per group of lanes (rays_sg_group.hpp); preferred by find_kernel
+    RAYS_ENTRY_GROUP(1), RAYS_ENTRY_GROUP(2), RAYS_ENTRY_GROUP(3), RAYS_ENTRY_GROUP(4), RAYS_ENTRY_GROUP(5), RAYS_ENTRY_GROUP(6),
+#endif
 #if RAYS_INST_SOLVER == 0 && RAYS_INST_EQ != 2
     // the common analytic-equilibrium shapes also built for two waves per SIMD (the eqdsk + damping
     // kernels lose at 128 VGPRs: 4.4 -> 7.0 ms on the 256k-ray eqdsk fan)

@@ -23,6 +23,7 @@ struct KernelEntry {
   int solver, eq, ns, deriv, nv;  // eq = equilibrium model | kEqUnitExp (the kernels' EQ argument)
   int occ;                        // waves per SIMD the kernel is built for (RK4: 1 and, for the common shapes, 2)
   int sg_far_per_lane;            // SG: doubles per lane of the upper-tier workspace (TraceArgs::sg_far); RK4: 0
+  int lanes_per_ray;              // 1, or G for the lane-group SG kernel (rays_sg_group.hpp)
   const char* name;
   // Launches on `stream` with a grid sized for full residency (persistent waves + lane refill).
   hipError_t (*launch)(const DevParams&, const TraceArgs&, hipStream_t stream, int* grid_blocks);
@@ -81,14 +82,15 @@ inline hipError_t kernel_occupancy(Kernel kernel, size_t lds_bytes, Occupancy* o
   return hipSuccess;
 }
 
+// rays_per_block: rays a block starts with (kBlock: one ray per lane; kBlock / G for the lane-group kernels)
 template <typename Kernel>
 inline hipError_t launch_persistent(Kernel kernel, size_t lds_bytes, const DevParams& P,
-                                    const TraceArgs& A, hipStream_t stream, int* grid_blocks) {
+                                    const TraceArgs& A, hipStream_t stream, int* grid_blocks, int rays_per_block = kBlock) {
   Occupancy occ;
   hipError_t e = kernel_occupancy(kernel, lds_bytes, &occ);
   if (e != hipSuccess) return e;
   const int cached_blocks_per_cu = occ.blocks_per_cu, cached_cus = occ.cus;
-  const long long need = ((long long)A.nray + kBlock - 1) / kBlock;
+  const long long need = ((long long)A.nray + rays_per_block - 1) / rays_per_block;
   long long resident = (long long)cached_blocks_per_cu * cached_cus;
   int blocks = (int)(need < resident ? need : resident);
   if (A.sg_far && (long long)blocks * kBlock > A.sg_far_lanes) blocks = (int)(A.sg_far_lanes / kBlock);

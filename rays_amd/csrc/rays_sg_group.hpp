@@ -10,21 +10,28 @@
 // phi(7,16) and six coefficient vectors per lane: 256 VGPRs + ~200 AGPRs + all of the LDS + a global workspace, one
 // wave per SIMD, ~13 clocks per bookkeeping instruction (nothing hides an LDS round trip), and a 65536-ray fan is
 // exactly one ray per resident lane: nothing to refill, the pass lasts as long as its longest ray while half the
-// SIMDs idle.  Here a ray owns G = 8 lanes:
-//   * lane j of the group evaluates the j-th central difference of deriv_num -- two determinants at two
-//     equilibria, the same code in every lane on different data (d/dx, d/dy, d/dz, d/dkx, d/dky, d/dkz, d/domega;
-//     the eighth lane evaluates the unperturbed equilibrium for the box test) -- and the seven differences are
-//     exchanged with __shfl; a right-hand side is 2 sub-evaluations deep instead of 20;
-//   * lane j also owns component j of the ODE vector: its row of the divided differences phi(j, 1:16) is SIXTEEN
-//     doubles in registers (no tiers, no workspace, no AGPR parking); predictor, corrector and difference updates
-//     (ode_RAYS.f90:985-1011, 1128-1164) are one operation per lane instead of seven, the weighted norms of `step`
-//     are gathered in the reference's summation order;
+// SIMDs idle.  Here a ray owns a group of G lanes (G = 4, a DPP quad, in the product; 8 and 16 build and are tested):
+//   * the group's lanes share deriv_num's seven central differences.  G = 4: lanes 0..2 take the position
+//     differences (two equilibria + two determinants each), lane 3 the unperturbed point (box test); then lanes 0..2
+//     take the wave-vector differences and lane 3 the frequency difference, all four at the unperturbed fields lane 3
+//     has just evaluated and broadcast.  A right-hand side is 2 equilibria + 4 determinants deep instead of 9 + 14;
+//     the differences are exchanged with DPP quad_perm moves (one full-rate VALU instruction per dword);
+//   * lane j owns components j and j + G of the ODE vector: its rows of the divided differences phi(l, 1:16) are
+//     registers for the orders in use (rows 1..6 + the round-off rows; the rest, reached in 0.03 % of the steps, in
+//     the launch's workspace); predictor, corrector and difference updates (ode_RAYS.f90:985-1011, 1128-1164) are
+//     two operations per lane instead of seven, the weighted norms of `step` are gathered in the reference's
+//     summation order;
 //   * the scalar part of `step` (order and step-size selection, the coefficient recurrences psi, alpha, beta, sig,
-//     g, v) is replicated in the group's lanes; the coefficient vectors live in one LDS column per RAY (672 bytes);
-//   * a wave holds 8 rays and needs ~1/3 of the registers, so several waves share a SIMD (their LDS round trips
-//     overlap) and a 64k fan is 8192 waves: finished groups pull the next ray, the idle tail is gone.
+//     g, v) is replicated in the group's lanes; the coefficient vectors and the rarely touched per-ray scalars live
+//     in LDS, one column per RAY;
+//   * a wave holds 16 rays in 168 VGPRs, three waves share a SIMD (their LDS round trips overlap), and a 64k fan is
+//     4096 waves: finished groups pull the next ray, most of the idle tail is gone.
+// What it costs: the scalar part of `step` is paid per 64 / G rays instead of per 64 (it does not shrink with G),
+// which is why small groups win: measured on the 64k-ray Solovev fan (cfg 3, ms per pass; one ray per lane: 296-311)
+// G = 8: 396 -> 327 (phi out of scratch, parameter loads per trip), G = 4: 266 -> 250 -> 242 (DPP, gstr table) ->
+// 234 (shared unperturbed equilibrium) -> 212 (three waves per SIMD).  DESIGN.md 4.4.
 // Every floating-point operation is the reference's, in its order: results are bit-identical to rays_sg.hpp's
-// and to the reference (tests/test_cpu_group_emul.py on the host wave emulator, tests/test_gpu_*).
+// and to the reference (tests/test_cpu_group_emul.py on the host wave emulator, tests/test_gpu_baseline_kernels.py).
 //
 // Cross-lane operations (__any, __ballot, __shfl) are only issued from wave-uniform control flow.
 #pragma once
@@ -39,16 +46,44 @@ struct GrpGeom {
   static constexpr int NV = 7;
   static constexpr int CPL = (NV + 1 + G - 1) / G;  // per lane: ODE components = difference pairs (7 + the base point)
   static constexpr int kBaseLane = NV % G, kBaseSlot = NV / G;  // who holds "pair 7", the unperturbed equilibrium
-  static constexpr int kRaysPerBlock = kBlock / G;
-  static constexpr int kCoefLen = 14, kCoefArrays = 6;
-  static constexpr size_t kLdsBytes = (size_t)kCoefArrays * kCoefLen * kRaysPerBlock * sizeof(double);
+  static constexpr int kThreads = 256;  // the launch block (rays_launch.hpp: kBlock)
+  static constexpr int kRaysPerBlock = kThreads / G;
+  static constexpr int kCoefLen = 14, kCoefArrays = 6, kScalars = 16;
+  static constexpr int kDoublesPerRay = kCoefArrays * kCoefLen + kScalars;
+  static constexpr size_t kLdsBytes = 0;  // (dynamic LDS: none -- the coefficient columns are static arrays of the kernel)
 };
 
 // value held by lane j of this lane's group (all lanes of the wave take part)
+#ifndef RAYS_HOST_EMUL
+// G = 4: a group is a quad, and DPP's quad_perm broadcasts lane j of every quad in ONE full-rate VALU move per dword
+// (immediate pattern: no address register, no trip through the LDS crossbar, nothing to wait for).
+template <int J>
+RAYS_DEV int quad_bcast(int x) {
+  return __builtin_amdgcn_update_dpp(x, x, J | (J << 2) | (J << 4) | (J << 6), 0xf, 0xf, false);
+}
+RAYS_DEV int quad_bcast_j(int x, int j) {  // j is a constant after unrolling: the switch folds away
+  switch (j & 3) {
+    case 0: return quad_bcast<0>(x);
+    case 1: return quad_bcast<1>(x);
+    case 2: return quad_bcast<2>(x);
+    default: return quad_bcast<3>(x);
+  }
+}
+#endif
 template <int G>
-RAYS_DEV double grp_bcast(double x, int j) { return __shfl(x, j, G); }
+RAYS_DEV int grp_bcast(int x, int j) {
+#ifndef RAYS_HOST_EMUL
+  if (G == 4) return quad_bcast_j(x, j);
+#endif
+  return __shfl(x, j, G);
+}
 template <int G>
-RAYS_DEV int grp_bcast(int x, int j) { return __shfl(x, j, G); }
+RAYS_DEV double grp_bcast(double x, int j) {
+#ifndef RAYS_HOST_EMUL
+  if (G == 4) return __hiloint2double(quad_bcast_j(__double2hiint(x), j), quad_bcast_j(__double2loint(x), j));
+#endif
+  return __shfl(x, j, G);
+}
 // sum over the ODE components in the reference's order l = 1..7 (component l lives in slot l / G of lane l % G)
 template <int G>
 RAYS_DEV double grp_sum(const double t[GrpGeom<G>::CPL]) {
@@ -62,8 +97,10 @@ RAYS_DEV double grp_sum(const double t[GrpGeom<G>::CPL]) {
 // Every lane of the group computes the same values and writes them (same address, same data); a lane only ever
 // reads back what it wrote itself.
 struct GCoef {
-  enum { PSI = 0, ALPHA, BETA, SIG, GG, V };
-  sg_lds_ptr col;
+  enum { PSI = 0, ALPHA, BETA, SIG, GG, V, SC, kArrays };
+  // One LDS array per coefficient vector (distinct objects: the compiler then knows that a write of beta(i) cannot
+  // change psi(i - 1) and does not wait for it), each [14][rays per block]; `a[x]` points at this ray's column.
+  sg_lds_ptr a[kArrays];
   int stride;
   struct Ref {
     sg_lds_ptr p;
@@ -71,7 +108,7 @@ struct GCoef {
     RAYS_DEV const Ref& operator=(double x) const { *p = x; return *this; }
     RAYS_DEV const Ref& operator=(const Ref& o) const { return *this = (double)o; }
   };
-  RAYS_DEV Ref at(int arr, int i) const { return Ref{col + (arr * 14 + i - 1) * stride}; }
+  RAYS_DEV Ref at(int arr, int i) const { return Ref{a[arr] + (i - 1) * stride}; }
   RAYS_DEV Ref psi(int i) const { return at(PSI, i); }      // 1..12
   RAYS_DEV Ref alpha(int i) const { return at(ALPHA, i); }  // 1..12
   RAYS_DEV Ref beta(int i) const { return at(BETA, i); }    // 1..12
@@ -80,118 +117,193 @@ struct GCoef {
   RAYS_DEV Ref v(int i) const { return at(V, i); }          // 1..12
   RAYS_DEV Ref wi(int i) const { return at(ALPHA, i); }     // intrp's w(1:14) reuses alpha (the integrator restarts after it)
   RAYS_DEV Ref gi(int i) const { return at(SIG, i); }       // intrp's g(1:13) reuses sig
+  // Per-ray scalars of trace_rays / SG_ode / de that are touched once or twice per trip (or per interval): kept in
+  // LDS, one column per ray, instead of in registers of every lane of the group.
+  enum { T_ = 0, TOUT, ABSDEL, TEND, RELEPS, ABSEPS, SOUT, DS_RAY, LAST_RESID, PREV_RESID, MAXR, REL_ERR, ABS_ERR, HOLD,
+         XOLD, ROUND };
+  RAYS_DEV Ref sc(int i) const { return Ref{a[SC] + i * stride}; }
 };
 
-// This lane's rows of the divided differences: phi(l, 1:16) for its C components, all in registers.  Rows are indexed
-// by the ray's order, so every loop over rows is unrolled with the ray's bounds as predicates; `cap` is a
-// wave-uniform bound on the row index (the largest order in the wave + what the caller adds), so the unrolled loops
-// end with a scalar branch.
+// This lane's rows of the divided differences phi(l, 1:16) for its C components.  Rows are indexed by the ray's
+// order k, which stays low because SG_ode restarts the integrator on every output interval (k <= 4 in 99.7 % of the
+// step attempts of the Solovev fan, k <= 6 in 99.97 %):
+//   rows 1..KR (= 6) and the two round-off rows 15, 16   registers; every loop over them is unrolled and BRANCH-FREE
+//                                                        (selects on the ray's bounds; `ncap` = a wave-uniform bound
+//                                                        on the rows in play ends the unrolled loop with a scalar branch)
+//   rows KR+1..14                                        the launch's global workspace (TraceArgs::sg_far, [slot][lane]);
+//                                                        reached behind a wave-uniform test `any_hi`
+// (a fully unrolled loop must not `break`: with an early exit LLVM leaves a rolled remainder, the rows are then
+// indexed dynamically and the whole array moves to scratch memory)
+#ifndef RAYS_SG_GROUP_KR
+#define RAYS_SG_GROUP_KR 6  // (tests/hip_emul builds a second library with 2, so that ordinary rays cross the tier boundary)
+#endif
 template <int C>
 struct GPhi {
-  double r[17][C];  // [1..16]
+  static constexpr int KR = RAYS_SG_GROUP_KR, kFarRows = 14 - KR, kFarDoubles = kFarRows * C;
+  static_assert(KR >= 2 && KR <= 12, "rows 1 and 2 are addressed directly");
+  double lo[KR + 2][C];  // [1..KR]; [KR+1] is a zero pad for the unrolled restore loop
+  double r15[C], r16[C];
+  double* far;           // this lane's workspace column
+  long long fstride;
+  RAYS_DEV double& hi(int q, int c) const { return far[((q - KR - 1) * C + c) * fstride]; }
   RAYS_DEV void clear() {
 #pragma unroll
-    for (int q = 0; q < 17; q++)
+    for (int q = 0; q < KR + 2; q++)
 #pragma unroll
-      for (int c = 0; c < C; c++) r[q][c] = 0.;
+      for (int c = 0; c < C; c++) lo[q][c] = 0.;
+#pragma unroll
+    for (int c = 0; c < C; c++) r15[c] = r16[c] = 0.;
   }
-  RAYS_DEV void get(int i, double out[C], int cap) const {  // out = phi(:, i); i outside 1..14: zeros
+  RAYS_DEV void get(int i, double out[C], bool any_hi) const {  // out = phi(:, i); i outside 1..14: zeros
 #pragma unroll
     for (int c = 0; c < C; c++) out[c] = 0.;
 #pragma unroll
-    for (int q = 1; q <= 14; q++) {
-      if (q > cap) break;
-      if (i == q) {
+    for (int q = 1; q <= KR; q++)
 #pragma unroll
-        for (int c = 0; c < C; c++) out[c] = r[q][c];
+      for (int c = 0; c < C; c++) out[c] = i == q ? lo[q][c] : out[c];
+    if (RAYS_RARE(any_hi)) {
+      if (i > KR && i <= 14) {
+#pragma unroll
+        for (int c = 0; c < C; c++) out[c] = hi(i, c);
       }
     }
   }
-  RAYS_DEV void set(int i, const double in[C], int cap) {
+  RAYS_DEV void set(int i, const double in[C], bool any_hi) {
 #pragma unroll
-    for (int q = 1; q <= 14; q++) {
-      if (q > cap) break;
-      if (i == q) {
+    for (int q = 1; q <= KR; q++)
 #pragma unroll
-        for (int c = 0; c < C; c++) r[q][c] = in[c];
+      for (int c = 0; c < C; c++) lo[q][c] = i == q ? in[c] : lo[q][c];
+    if (RAYS_RARE(any_hi)) {
+      if (i > KR && i <= 14) {
+#pragma unroll
+        for (int c = 0; c < C; c++) hi(i, c) = in[c];
       }
     }
   }
   // phi(:, i) = beta(i) * phi(:, i), i = a..b                       (ode_RAYS.f90:992-996)
-  RAYS_DEV void scale(int a, int b, const GCoef& S, int cap) {
+  RAYS_DEV void scale(int a, int b, const GCoef& S, int ncap, bool any_hi) {
 #pragma unroll
-    for (int q = 1; q <= 12; q++) {
-      if (q > cap) break;
-      if (q >= a && q <= b) {
+    for (int q = 1; q <= KR; q++) {
+      if (q > ncap) continue;
+      const bool on = q >= a && q <= b;
+      const double bq = S.beta(q);
+#pragma unroll
+      for (int c = 0; c < C; c++) lo[q][c] = on ? bq * lo[q][c] : lo[q][c];
+    }
+    if (RAYS_RARE(any_hi)) {
+      for (int q = a > KR + 1 ? a : KR + 1; q <= b; q++) {
         const double bq = S.beta(q);
 #pragma unroll
-        for (int c = 0; c < C; c++) r[q][c] = bq * r[q][c];
+        for (int c = 0; c < C; c++) hi(q, c) = bq * hi(q, c);
       }
     }
   }
   // predictor (:1003-1011), i = k..1:  p += phi(:,i)*g(i); phi(:,i) += phi(:,i+1)   (phi(:,k+1) has just been zeroed)
-  RAYS_DEV void predict(int k, const GCoef& S, double pp[C], int cap) {
+  RAYS_DEV void predict(int k, const GCoef& S, double pp[C], int ncap, bool any_hi) {
     double up[C];
 #pragma unroll
     for (int c = 0; c < C; c++) up[c] = 0.;
-#pragma unroll
-    for (int q = 12; q >= 1; q--) {
-      if (q > cap) continue;
-      if (q <= k) {
+    if (RAYS_RARE(any_hi)) {
+      for (int q = k; q > KR; q--) {
         const double gg = S.g(q);
 #pragma unroll
         for (int c = 0; c < C; c++) {
-          double x = r[q][c];
+          double x = hi(q, c);
           pp[c] = pp[c] + x * gg;
           x = x + up[c];
-          r[q][c] = x;
+          hi(q, c) = x;
           up[c] = x;
         }
       }
     }
+#pragma unroll
+    for (int q = KR; q >= 1; q--) {
+      if (q > ncap) continue;
+      const bool on = q <= k;
+      const double gg = S.g(q);
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const double x = lo[q][c];
+        const double pn = pp[c] + x * gg, xn = x + up[c];
+        pp[c] = on ? pn : pp[c];
+        lo[q][c] = on ? xn : x;
+        up[c] = on ? xn : up[c];
+      }
+    }
   }
   // failed step (:1090-1094), i = 1..k ascending:  phi(:,i) = (phi(:,i) - phi(:,i+1)) / beta(i)
-  RAYS_DEV void restore(int k, const GCoef& S, int cap) {
+  RAYS_DEV void restore(int k, const GCoef& S, int ncap, bool any_hi) {
+    double nxt[C];  // phi(:, KR+1), not yet modified when row KR is restored
 #pragma unroll
-    for (int q = 1; q <= 12; q++) {
-      if (q > cap) break;
-      if (q <= k) {
+    for (int c = 0; c < C; c++) nxt[c] = 0.;
+    if (RAYS_RARE(any_hi)) {
+      if (k >= KR) {
+#pragma unroll
+        for (int c = 0; c < C; c++) nxt[c] = hi(KR + 1, c);
+      }
+    }
+#pragma unroll
+    for (int q = 1; q <= KR; q++) {
+      if (q > ncap) continue;
+      const bool on = q <= k;
+      const Recip b = make_recip(S.beta(q));
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const double above = q < KR ? lo[q + 1][c] : nxt[c];  // old value: rows are restored in ascending order
+        const double x = div(lo[q][c] - above, b);
+        lo[q][c] = on ? x : lo[q][c];
+      }
+    }
+    if (RAYS_RARE(any_hi)) {
+      for (int q = KR + 1; q <= k; q++) {
         const Recip b = make_recip(S.beta(q));
 #pragma unroll
-        for (int c = 0; c < C; c++) r[q][c] = div(r[q][c] - r[q + 1][c], b);
+        for (int c = 0; c < C; c++) hi(q, c) = div(hi(q, c) - hi(q + 1, c), b);
       }
     }
   }
   // phi(:, i) += d, i = 1..k                                         (:1160-1164)
-  RAYS_DEV void add(int k, const double d[C], int cap) {
+  RAYS_DEV void add(int k, const double d[C], int ncap, bool any_hi) {
 #pragma unroll
-    for (int q = 1; q <= 12; q++) {
-      if (q > cap) break;
-      if (q <= k) {
+    for (int q = 1; q <= KR; q++) {
+      if (q > ncap) continue;
 #pragma unroll
-        for (int c = 0; c < C; c++) r[q][c] = r[q][c] + d[c];
-      }
+      for (int c = 0; c < C; c++) lo[q][c] = q <= k ? lo[q][c] + d[c] : lo[q][c];
+    }
+    if (RAYS_RARE(any_hi)) {
+      for (int q = KR + 1; q <= k; q++)
+#pragma unroll
+        for (int c = 0; c < C; c++) hi(q, c) = hi(q, c) + d[c];
     }
   }
   // intrp (:1343-1349), i = ki..1:  yout += g(i) * phi(:, i)
-  RAYS_DEV void interp(int ki, const GCoef& S, double yout[C], int cap) const {
-#pragma unroll
-    for (int q = 13; q >= 1; q--) {
-      if (q > cap) continue;
-      if (q <= ki) {
+  RAYS_DEV void interp(int ki, const GCoef& S, double yout[C], bool any_hi) const {
+    if (RAYS_RARE(any_hi)) {
+      for (int q = ki; q > KR; q--) {
         const double gg = S.gi(q);
 #pragma unroll
-        for (int c = 0; c < C; c++) yout[c] = yout[c] + gg * r[q][c];
+        for (int c = 0; c < C; c++) yout[c] = yout[c] + gg * hi(q, c);
       }
+    }
+#pragma unroll
+    for (int q = KR; q >= 1; q--) {
+      const bool on = q <= ki;
+      const double gg = S.gi(q);
+#pragma unroll
+      for (int c = 0; c < C; c++) yout[c] = on ? yout[c] + gg * lo[q][c] : yout[c];
     }
   }
 };
+// doubles per lane of the launch's workspace (TraceArgs::sg_far) the lane-group kernel needs
+template <int G>
+constexpr int sg_group_far_doubles_per_lane() { return GPhi<GrpGeom<G>::CPL>::kFarDoubles; }
 
 // Equilibrium for determ at a (possibly perturbed) point; returns the equilibrium's stop code when check_box is set
 // (the group's base lane: equilibrium_m.f90:198-202, eqn_ray.f90:90-102).
 template <int EQ, int NS>
 RAYS_DEV int eq_for_determ_err(const DevParams& P, const Recip& Romgrf, const Recip& Romgrf2, const double rvec[3],
-                               double bunit[3], double alpha[NS], double gamma[NS], bool check_box) {
+                               double bunit[3], double alpha[NS], double gamma[NS], bool check_box,
+                               double* omgc = nullptr, double* omgp2 = nullptr) {
   EqPoint<NS> e;
   equilibrium<EQ, NS>(P, Romgrf, Romgrf2, rvec, e, check_box);
 #pragma unroll
@@ -200,6 +312,8 @@ RAYS_DEV int eq_for_determ_err(const DevParams& P, const Recip& Romgrf, const Re
   for (int is = 0; is < NS; is++) {
     alpha[is] = e.alpha[is];
     gamma[is] = e.gamma[is];
+    if (omgc) omgc[is] = e.omgc[is];
+    if (omgp2) omgp2[is] = e.omgp2[is];
   }
   return e.err;
 }
@@ -210,8 +324,9 @@ RAYS_DEV int eq_for_determ_err(const DevParams& P, const Recip& Romgrf, const Re
 //   deriv_num.f90:40-84: dddx(i) = (D(r + delta e_i) - D(r - delta e_i)) / (2 delta), dddk(i) likewise with
 //   change = max(delta, |delta k_i|) / 2, dddw from omgrf (1 +- delta/2) with k0 rescaled; D = determ (:99-153).
 template <int EQ, int NS, int G>
-RAYS_DEV void group_rhs(const DevParams& P, const double win[GrpGeom<G>::CPL], int gl, bool do_check, bool any_check,
+RAYS_DEV void group_rhs(const DevParams& P_in, const double win[GrpGeom<G>::CPL], int gl, bool do_check, bool any_check,
                         double f[GrpGeom<G>::CPL], int& code, double& resid, int& cs_flag, bool& cs_stop) {
+  const DevParams& P = cold_params(P_in);  // the run constants are loaded here, per trip (rays_trace.hpp)
   typedef GrpGeom<G> GEO;
   constexpr int C = GEO::CPL;
   double v[7];
@@ -220,39 +335,135 @@ RAYS_DEV void group_rhs(const DevParams& P, const double win[GrpGeom<G>::CPL], i
   const double rvec[3] = {v[0], v[1], v[2]}, kvec[3] = {v[3], v[4], v[5]};
   double d[C];
   int err_base = 0;
+  double dd[7];
+  int err;
+  if constexpr (G == 4) {
+    // Four lanes, two slots.  Slot 0: lanes 0..2 take the position differences (two equilibria + two determinants
+    // each), lane 3 the unperturbed point (box test).  Slot 1: lanes 0..2 the wave-vector differences, lane 3 the
+    // frequency difference -- all four at the UNPERTURBED fields (deriv_num.f90:60-80), which lane 3 has just
+    // evaluated: its bunit, alpha, gamma (and, for the frequency difference, omgc and omgp2, of which alpha and gamma
+    // are the quotients by omgrf**2 and omgrf: equilibrium_m.f90:262-265) are broadcast instead of evaluating the
+    // equilibrium eight more times.  Same operands, same operations: same bits.
+    const Recip Ro0 = const_recip(P.omgrf, P.inv_omgrf), Ro20 = const_recip(P.omgrf2, P.inv_omgrf2);
+    const Recip Rk00 = const_recip(P.k0, P.inv_k0);
+    double b0[3], a0[NS], g0[NS], oc0[NS], op0[NS];
+#pragma unroll
+    for (int i = 0; i < 3; i++) b0[i] = 0.;
+#pragma unroll
+    for (int is = 0; is < NS; is++) a0[is] = g0[is] = oc0[is] = op0[is] = 0.;
+    {
+      double det_plus = 0., det_minus = 0.;
+#pragma unroll 1
+      for (int sgn = 0; sgn < 2; sgn++) {
+        const bool plus = sgn == 0;
+        const double dr = plus ? P.delta : -P.delta;
+        double rr[3], bu[3], al[NS], ga[NS], oc[NS], op[NS];
+#pragma unroll
+        for (int i = 0; i < 3; i++) rr[i] = (gl == i) ? rvec[i] + dr : rvec[i];  // :42-43, :48
+        const int e1 = eq_for_determ_err<EQ, NS>(P, Ro0, Ro20, rr, bu, al, ga, plus && gl == 3, oc, op);
+        const double det = determ<NS>(bu, al, ga, kvec, Rk00);
+        if (plus) {
+          det_plus = det;
+          err_base = e1;  // (lane 3's is the one that is read)
+#pragma unroll
+          for (int i = 0; i < 3; i++) b0[i] = bu[i];
+#pragma unroll
+          for (int is = 0; is < NS; is++) {
+            a0[is] = al[is];
+            g0[is] = ga[is];
+            oc0[is] = oc[is];
+            op0[is] = op[is];
+          }
+        } else {
+          det_minus = det;
+        }
+      }
+      d[0] = (det_plus - det_minus) / P.two_delta;  // :50
+    }
+    // the unperturbed point's fields, from lane 3
+#pragma unroll
+    for (int i = 0; i < 3; i++) b0[i] = grp_bcast<G>(b0[i], 3);
+#pragma unroll
+    for (int is = 0; is < NS; is++) {
+      a0[is] = grp_bcast<G>(a0[is], 3);
+      g0[is] = grp_bcast<G>(g0[is], 3);
+      oc0[is] = grp_bcast<G>(oc0[is], 3);
+      op0[is] = grp_bcast<G>(op0[is], 3);
+    }
+    {
+      const bool w = gl == 3;
+      const double kc = gl == 0 ? kvec[0] : (gl == 1 ? kvec[1] : kvec[2]);
+      const double change = fmax(P.delta, fabs(P.delta * kc)) / 2.;  // :61
+      double det_plus = 0., det_minus = 0.;
+#pragma unroll 1
+      for (int sgn = 0; sgn < 2; sgn++) {
+        const bool plus = sgn == 0;
+        const double dk = plus ? change : -change;
+        double kk[3], al[NS], ga[NS];
+#pragma unroll
+        for (int i = 0; i < 3; i++) kk[i] = (gl == i) ? kvec[i] + dk : kvec[i];  // :62, :65
+        const Recip Ro = const_recip(plus ? P.omgrf_p : P.omgrf_m, plus ? P.inv_omgrf_p : P.inv_omgrf_m);
+        const Recip Ro2 = const_recip(plus ? P.omgrf2_p : P.omgrf2_m, plus ? P.inv_omgrf2_p : P.inv_omgrf2_m);
+        const Recip Rk = const_recip(w ? (plus ? P.k0_p : P.k0_m) : P.k0, w ? (plus ? P.inv_k0_p : P.inv_k0_m) : P.inv_k0);
+#pragma unroll
+        for (int is = 0; is < NS; is++) {  // :71-80 on the frequency lane
+          const double aw = div(op0[is], Ro2), gw = div(oc0[is], Ro);
+          al[is] = w ? aw : a0[is];
+          ga[is] = w ? gw : g0[is];
+        }
+        const double det = determ<NS>(b0, al, ga, kk, Rk);
+        if (plus) det_plus = det;
+        else det_minus = det;
+      }
+      d[1] = (det_plus - det_minus) / (w ? P.omgrf0_delta : 2. * change);  // :63, :80
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      dd[i] = grp_bcast<G>(d[0], i);
+      dd[3 + i] = grp_bcast<G>(d[1], i);
+    }
+    dd[6] = grp_bcast<G>(d[1], 3);
+    err = grp_bcast<G>(err_base, 3);
+  } else {
 #pragma unroll
   for (int c = 0; c < C; c++) {
     const int p = gl + G * c;  // 0..2: d/dx_p   3..5: d/dk_(p-3)   6: d/domega   7: the unperturbed point (box test)   > 7: none
-    double rp[3], rm[3], kp[3], km[3], two_change = 0.;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-      rp[i] = (p == i) ? rvec[i] + P.delta : rvec[i];  // :42-43
-      rm[i] = (p == i) ? rvec[i] - P.delta : rvec[i];  // :48
-      const double change = fmax(P.delta, fabs(P.delta * kvec[i])) / 2.;  // :61
-      kp[i] = (p == 3 + i) ? kvec[i] + change : kvec[i];
-      km[i] = (p == 3 + i) ? kvec[i] - change : kvec[i];
-      if (p == 3 + i) two_change = 2. * change;
-    }
+    // :61 change = max(delta, |delta k_i|) / 2 of this lane's wave-vector component (p = 3..5)
+    const double kc = p == 3 ? kvec[0] : (p == 4 ? kvec[1] : kvec[2]);
+    const double change = fmax(P.delta, fabs(P.delta * kc)) / 2.;
     const bool w = p == 6;  // :71-80: per-lane omgrf / k0 (the reference rewrites its module variables)
-    const Recip Rop = const_recip(w ? P.omgrf_p : P.omgrf, w ? P.inv_omgrf_p : P.inv_omgrf);
-    const Recip Rop2 = const_recip(w ? P.omgrf2_p : P.omgrf2, w ? P.inv_omgrf2_p : P.inv_omgrf2);
-    const Recip Rkp = const_recip(w ? P.k0_p : P.k0, w ? P.inv_k0_p : P.inv_k0);
-    const Recip Rom = const_recip(w ? P.omgrf_m : P.omgrf, w ? P.inv_omgrf_m : P.inv_omgrf);
-    const Recip Rom2 = const_recip(w ? P.omgrf2_m : P.omgrf2, w ? P.inv_omgrf2_m : P.inv_omgrf2);
-    const Recip Rkm = const_recip(w ? P.k0_m : P.k0, w ? P.inv_k0_m : P.inv_k0);
-    double bu[3], al[NS], ga[NS];
-    const int e1 = eq_for_determ_err<EQ, NS>(P, Rop, Rop2, rp, bu, al, ga, p == 7);
-    const double det_plus = determ<NS>(bu, al, ga, kp, Rkp);
-    (void)eq_for_determ_err<EQ, NS>(P, Rom, Rom2, rm, bu, al, ga, false);
-    const double det_minus = determ<NS>(bu, al, ga, km, Rkm);
-    const double den = p < 3 ? P.two_delta : (p < 6 ? two_change : P.omgrf0_delta);
+    // the two determinants of the difference, one after the other through ONE copy of the code (rolled loop: half
+    // the instructions and half the live registers of two inlined evaluations); a - b is a + (-b) bit for bit
+    double det_plus = 0., det_minus = 0.;
+#pragma unroll 1
+    for (int sgn = 0; sgn < 2; sgn++) {
+      const bool plus = sgn == 0;
+      const double dr = plus ? P.delta : -P.delta, dk = plus ? change : -change;
+      double rr[3], kk[3], bu[3], al[NS], ga[NS];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        rr[i] = (p == i) ? rvec[i] + dr : rvec[i];      // :42-43, :48
+        kk[i] = (p == 3 + i) ? kvec[i] + dk : kvec[i];  // :62, :65
+      }
+      const Recip Ro = const_recip(w ? (plus ? P.omgrf_p : P.omgrf_m) : P.omgrf, w ? (plus ? P.inv_omgrf_p : P.inv_omgrf_m) : P.inv_omgrf);
+      const Recip Ro2 = const_recip(w ? (plus ? P.omgrf2_p : P.omgrf2_m) : P.omgrf2, w ? (plus ? P.inv_omgrf2_p : P.inv_omgrf2_m) : P.inv_omgrf2);
+      const Recip Rk = const_recip(w ? (plus ? P.k0_p : P.k0_m) : P.k0, w ? (plus ? P.inv_k0_p : P.inv_k0_m) : P.inv_k0);
+      const int e1 = eq_for_determ_err<EQ, NS>(P, Ro, Ro2, rr, bu, al, ga, plus && p == 7);
+      const double det = determ<NS>(bu, al, ga, kk, Rk);
+      if (plus) {
+        det_plus = det;
+        if (p == 7) err_base = e1;
+      } else {
+        det_minus = det;
+      }
+    }
+    const double den = p < 3 ? P.two_delta : (p < 6 ? 2. * change : P.omgrf0_delta);
     d[c] = (det_plus - det_minus) / den;  // :50, :63, :80
-    if (p == 7) err_base = e1;
   }
-  double dd[7];
 #pragma unroll
   for (int p = 0; p < 7; p++) dd[p] = grp_bcast<G>(d[p / G], p % G);
-  const int err = grp_bcast<G>(err_base, GEO::kBaseLane);
+  err = grp_bcast<G>(err_base, GEO::kBaseLane);
+  }
   const double dddx[3] = {dd[0], dd[1], dd[2]}, dddk[3] = {dd[3], dd[4], dd[5]};
   double dvds[7];
 #pragma unroll
@@ -290,9 +501,15 @@ RAYS_DEV void group_rhs(const DevParams& P, const double win[GrpGeom<G>::CPL], i
   }
 }
 
+#ifndef RAYS_SG_GROUP_WAVES
+// waves per SIMD the kernel is compiled for (register budget 512 / this).  Measured on the 64k-ray Solovev fan, G = 4:
+// 2 waves (256 VGPRs, 1 spill) 235 ms, 3 waves (168 VGPRs, 141 spills -- most of them in check_save's share, which
+// runs once per output interval) 212 ms, 4 waves (128 VGPRs) 331 ms.
+#define RAYS_SG_GROUP_WAVES 3
+#endif
 #ifndef RAYS_HOST_EMUL
 template <int EQ, int NS, int G>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, RAYS_SG_GROUP_WAVES)
 sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
 #else
 template <int EQ, int NS, int G>
@@ -301,16 +518,47 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
 {
   typedef GrpGeom<G> GEO;
   constexpr int C = GEO::CPL, NV = 7;
-  DevParams P;
-  hot_params<EQ, NS>(P_kernarg, P);
+  // (no hot_params copy into vector registers: this kernel is built for several waves per SIMD, where registers are
+  // what is scarce and a scalar load of a run constant is hidden by the other waves)
+  const DevParams& P = P_kernarg;
   extern __shared__ double lds[];
   const int gl = threadIdx.x & (G - 1);  // lane within the ray's group
   const int gib = threadIdx.x / G;       // group within the block
   GCoef S;
-  S.col = (sg_lds_ptr)(lds + gib);
-  S.stride = GEO::kRaysPerBlock;
+#ifdef RAYS_HOST_EMUL
+  // (the host wave emulator runs the lanes of a wave one after the other between cross-lane operations, not in
+  // lock step: a column shared by the group's lanes would be read by one lane after another has updated it, so
+  // there every lane keeps a copy of its own; the values are the same)
+  double coef_private[GCoef::kArrays][16];
+  for (int x = 0; x < GCoef::kArrays; x++) S.a[x] = coef_private[x];
+  S.stride = 1;
+  (void)lds;
+#else
+  {
+    constexpr int R = GEO::kRaysPerBlock;
+    __shared__ double s_psi[14 * R], s_alpha[14 * R], s_beta[14 * R], s_sig[14 * R], s_g[14 * R], s_v[14 * R], s_sc[16 * R];
+    S.a[GCoef::PSI] = (sg_lds_ptr)(s_psi + gib);
+    S.a[GCoef::ALPHA] = (sg_lds_ptr)(s_alpha + gib);
+    S.a[GCoef::BETA] = (sg_lds_ptr)(s_beta + gib);
+    S.a[GCoef::SIG] = (sg_lds_ptr)(s_sig + gib);
+    S.a[GCoef::GG] = (sg_lds_ptr)(s_g + gib);
+    S.a[GCoef::V] = (sg_lds_ptr)(s_v + gib);
+    S.a[GCoef::SC] = (sg_lds_ptr)(s_sc + gib);
+    S.stride = R;
+  }
+  // gstr(1:13) (ode_RAYS.f90:776-779) as a table in LDS: indexed by the ray's order, a lookup instead of rays_sg.hpp's
+  // select chain over thirteen constants (which costs ~40 instructions a call, four calls per step)
+  __shared__ double s_gstr[16];
+  if (threadIdx.x < 14) s_gstr[threadIdx.x] = gstr((int)threadIdx.x);
+  __syncthreads();
+  const sg_lds_ptr gstr_tab = (sg_lds_ptr)s_gstr;
+  (void)lds;
+#define gstr(i) (gstr_tab[(i)])
+#endif
   GPhi<C> F;
   F.clear();
+  F.fstride = (long long)gridDim.x * blockDim.x;
+  F.far = cold_args(A_hot).sg_far + ((long long)blockIdx.x * blockDim.x + threadIdx.x);
   bool valid[C];  // this lane's slot holds an ODE component
 #pragma unroll
   for (int c = 0; c < C; c++) valid[c] = gl + G * c < NV;
@@ -327,14 +575,28 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
   bool need_init = alive;
   int pc = PC_CHECK;
   int nstep = 0;
-  double sout = 0.;
-  double ds_ray = P.ds;
-  double last_resid = 0., prev_resid = 0., maxr = -1.7976931348623157e308;
   double yy[C], pp[C], ysave[C];  // (lane) y of `step`, the predicted p, y of SG_ode (the state `ode` last returned)
   Recip wt[C];                    // (lane)
-  double t = 0., tout = 0., x = 0., h = 0., hold = 0., eps = 0.;
-  double rel_err = 0., abs_err = 0., releps = 0., abseps = 0., absdel = 0., tend = 0.;
-  double p5eps = 0., round_ = 0., xold = 0., absh = 0., erk = 0., erkm1 = 0.;
+  double x = 0., h = 0., eps = 0.;
+  double p5eps = 0., absh = 0., erk = 0., erkm1 = 0.;
+  // (t, tout, absdel, tend, releps, abseps, sout, ds_ray, the residual statistics, rel_err, abs_err, hold, xold, round:
+  // in the ray's LDS column, GCoef::sc)
+#define t S.sc(GCoef::T_)
+#define tout S.sc(GCoef::TOUT)
+#define absdel S.sc(GCoef::ABSDEL)
+#define tend S.sc(GCoef::TEND)
+#define releps S.sc(GCoef::RELEPS)
+#define abseps S.sc(GCoef::ABSEPS)
+#define sout S.sc(GCoef::SOUT)
+#define ds_ray S.sc(GCoef::DS_RAY)
+#define last_resid S.sc(GCoef::LAST_RESID)
+#define prev_resid S.sc(GCoef::PREV_RESID)
+#define maxr S.sc(GCoef::MAXR)
+#define rel_err S.sc(GCoef::REL_ERR)
+#define abs_err S.sc(GCoef::ABS_ERR)
+#define hold S.sc(GCoef::HOLD)
+#define xold S.sc(GCoef::XOLD)
+#define round_ S.sc(GCoef::ROUND)
   int k = 1, kold = 0, ns = 0, knew = 1, ifail = 0, nostep = 0, kle4 = 0;
   int resume = SEG_WAIT;
   int waited = 0;
@@ -346,11 +608,15 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
     wt[c] = make_recip(1.0);
   }
 
+  SG_PROF_DECL
   while (__any(alive)) {
+    SG_PROF(0);  // loop, refill
     if (RAYS_RARE(need_init)) {  // ray_tracing.f90:77-93, SG_ode_m.f90:73-85
       const TraceArgs& A = cold_args(A_hot);
-      double v0[NV];
-      start_ray<EQ, NS, NV>(P, A, ray, v0, sout, ds_ray);
+      double v0[NV], s_start = 0., ds_start = 0.;
+      start_ray<EQ, NS, NV>(P, A, ray, v0, s_start, ds_start);
+      sout = s_start;
+      ds_ray = ds_start;
 #pragma unroll
       for (int c = 0; c < C; c++) {
         yy[c] = 0.;
@@ -380,7 +646,8 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
       kcap = q + 1;
     }
     if (kcap > 12) kcap = 12;
-    const int rcap = kcap + 2;  // rows up to k + 2
+    const int ncap = kcap < GPhi<C>::KR ? kcap : GPhi<C>::KR;  // register rows in play
+    const bool any_hi = kcap + 2 > GPhi<C>::KR;                 // a ray of this wave may touch the workspace rows
 
     // ---- which lanes does this trip's right-hand side serve (phase and interval alignment: rays_sg.hpp) -------------
     const bool in_f2 = pc == PC_F2;
@@ -416,7 +683,15 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
     for (int c = 0; c < C; c++) win[c] = pc == PC_F2 ? pp[c] : yy[c];
     const bool do_check = act && pc == PC_CHECK;
     const bool any_check = __any(do_check);
+    SG_PROF(1);  // init, order cap, phase vote
+#ifdef RAYS_SG_PROFILE
+    prof_acc[25] += __popcll(__ballot(act));
+    prof_acc[26] += 1;
+    prof_acc[27] += __popcll(__ballot(alive));
+    prof_acc[28] += __popcll(__ballot(alive && at_check && !act));
+#endif
     group_rhs<EQ, NS, G>(P, win, gl, do_check, any_check, f, code, resid, cs_flag, cs_stop);
+    SG_PROF(any_check ? 15 : 2);  // RHS (slot 15: trips that also run check_save)
 
     // ---- per-ray continuation (flat control flow, segments in pipeline order: rays_sg.hpp) -------------------------
     int stop = 0;
@@ -489,6 +764,7 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
     }
 
     // ---- AFTER_F2: error estimates, accept or reject (ode_RAYS.f90:1020-1120) -------------------------------------
+    SG_PROF(3);  // CHECK bookkeeping
     {
       const bool here = seg == SEG_AFTER_F2 && !code;
       if (RAYS_RARE(seg == SEG_AFTER_F2 && code)) {  // :1020
@@ -498,11 +774,11 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
       if (__any(here)) {  // wave-uniform
         const int kp1 = k + 1, km1 = k - 1, km2 = k - 2;
         double rk[C], rkm1[C], tm2[C], tm1[C], t0[C];
-        F.get(k, rk, rcap);
-        F.get(km1, rkm1, rcap);
+        F.get(k, rk, any_hi);
+        F.get(km1, rkm1, any_hi);
 #pragma unroll
         for (int c = 0; c < C; c++) {
-          const double ph1 = F.r[1][c];
+          const double ph1 = F.lo[1][c];
           const double q2 = div(rkm1[c] + f[c] - ph1, wt[c]);
           const double q1 = div(rk[c] + f[c] - ph1, wt[c]);
           const double q0 = div(f[c] - ph1, wt[c]);
@@ -532,13 +808,13 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
             if (!(fl & FL_NORND)) {
 #pragma unroll
               for (int c = 0; c < C; c++) {
-                const double rho = hg * (f[c] - F.r[1][c]) - F.r[16][c];
+                const double rho = hg * (f[c] - F.lo[1][c]) - F.r16[c];
                 yy[c] = pp[c] + rho;
-                F.r[15][c] = (yy[c] - pp[c]) - rho;
+                F.r15[c] = (yy[c] - pp[c]) - rho;
               }
             } else {
 #pragma unroll
-              for (int c = 0; c < C; c++) yy[c] = pp[c] + hg * (f[c] - F.r[1][c]);
+              for (int c = 0; c < C; c++) yy[c] = pp[c] + hg * (f[c] - F.lo[1][c]);
             }
             pc = PC_F3;
             seg = SEG_WAIT;
@@ -546,7 +822,7 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
             // ---- failed step: restore, shrink (:1086-1120) ----
             fl &= ~FL_PHASE1;
             x = xold;
-            F.restore(k, S, kcap);
+            F.restore(k, S, ncap, any_hi);
             for (int i = 2; i <= k; i++) S.psi(i - 1) = S.psi(i) - h;
             ifail = ifail + 1;
             double temp2 = 0.5;
@@ -569,6 +845,7 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
     }
 
     // ---- AFTER_F3: update differences, choose order and step size (:1145-1231) ---------------------------------------
+    SG_PROF(4);
     {
       const bool here = seg == SEG_AFTER_F3 && !code;
       if (RAYS_RARE(seg == SEG_AFTER_F3 && code)) {  // :1145
@@ -578,19 +855,19 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
       if (__any(here)) {  // wave-uniform
         const int kp1 = k + 1, kp2 = k + 2, km1 = k - 1;
         double d1[C], d2[C], tp[C];
-        F.get(kp2, d2, rcap);
+        F.get(kp2, d2, any_hi);
 #pragma unroll
         for (int c = 0; c < C; c++) {
-          d1[c] = f[c] - F.r[1][c];
+          d1[c] = f[c] - F.lo[1][c];
           d2[c] = d1[c] - d2[c];
           const double q = div(d2[c], wt[c]);
           tp[c] = q * q;
         }
         const double sp = grp_sum<G>(tp);
         if (here) {
-          F.set(kp1, d1, rcap);
-          F.set(kp2, d2, rcap);
-          F.add(k, d1, kcap);
+          F.set(kp1, d1, any_hi);
+          F.set(kp2, d2, any_hi);
+          F.add(k, d1, ncap, any_hi);
           double erkp1 = 0.0;
           if (knew == km1 || k == 12) fl &= ~FL_PHASE1;
           if (fl & FL_PHASE1) {
@@ -639,6 +916,7 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
     }
 
     if (RAYS_RARE(seg == SEG_CRASH)) {  // de returns iflag = 3 (:566-575), SG_ode_m.f90:139-149
+    SG_PROF(5);
       rel_err = eps * releps;
       abs_err = eps * abseps;
 #pragma unroll
@@ -684,6 +962,7 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
     }
 
     // ---- DE_TOP: interval complete (intrp), or the entry of `step` (:511-556, 833-885) ------------------------------
+    SG_PROF(7);  // CRASH + DE_BEGIN
     {
       const bool top = seg == SEG_DE_TOP;
       const bool finish = top && absdel <= fabs(x - t);
@@ -714,7 +993,7 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
         double yout[C];
 #pragma unroll
         for (int c = 0; c < C; c++) yout[c] = 0.0;
-        F.interp(ki, S, yout, kcap + 1);
+        F.interp(ki, S, yout, any_hi);
 #pragma unroll
         for (int c = 0; c < C; c++) {
           yy[c] = yy[c] + hi * yout[c];
@@ -769,6 +1048,7 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
     }
 
     // ---- START_DONE: first step of an interval (:863-885) ------------------------------------------------------------
+    SG_PROF(8);
     {
       const bool here = seg == SEG_START_DONE && !code;
       if (RAYS_RARE(seg == SEG_START_DONE && code)) {  // :863
@@ -787,8 +1067,8 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
           have_f = 0;
 #pragma unroll
           for (int c = 0; c < C; c++) {
-            F.r[1][c] = f[c];
-            F.r[2][c] = 0.0;
+            F.lo[1][c] = f[c];
+            F.lo[2][c] = 0.0;
           }
           const double total = sqrt(sm);
           absh = fabs(h);
@@ -803,7 +1083,7 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
           if (p5eps <= 100.0 * round_) {
             fl &= ~FL_NORND;
 #pragma unroll
-            for (int c = 0; c < C; c++) F.r[15][c] = 0.0;
+            for (int c = 0; c < C; c++) F.r15[c] = 0.0;
           }
           ifail = 0;
           seg = SEG_COEF;
@@ -812,6 +1092,7 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
     }
 
     // ---- COEF: coefficients + predictor (:892-1015) ------------------------------------------------------------------
+    SG_PROF(9);
     if (seg == SEG_COEF) {
       const int kp1 = k + 1, kp2 = k + 2;
       if (h != hold) ns = 0;
@@ -837,7 +1118,7 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
         if (ns <= 1) {
 #pragma unroll
           for (int iq = 1; iq <= 12; iq++) {
-            if (iq > kcap) break;
+            if (iq > kcap) continue;
             if (iq <= k) {
               const double cq = 1.0 / (double)(iq * (iq + 1));
               S.v(iq) = cq;
@@ -856,7 +1137,7 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
           const int lim = kp1 - ns;
 #pragma unroll
           for (int iq = 1; iq <= 12; iq++) {  // ascending: v(iq+1) is still the old value
-            if (iq > kcap) break;
+            if (iq > kcap) continue;
             if (iq <= lim) {
               const double cq = S.v(iq) - a_ns * S.v(iq + 1);
               S.v(iq) = cq;
@@ -870,31 +1151,34 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
           const int lim = kp2 - i;
 #pragma unroll
           for (int iq = 1; iq <= 12; iq++) {
-            if (iq > kcap) break;
+            if (iq > kcap) continue;
             if (iq <= lim) w[iq] = w[iq] - a * w[iq + 1];
           }
           S.g(i) = w[1];
         }
       }
-      F.scale(nsp1, k, S, kcap);
+      SG_PROF(12);  // coefficient block
+      F.scale(nsp1, k, S, ncap, any_hi);
       {
         double row[C];
-        F.get(kp1, row, rcap);
-        F.set(kp2, row, rcap);  // phi(:,kp2) = phi(:,kp1)
+        F.get(kp1, row, any_hi);
+        F.set(kp2, row, any_hi);  // phi(:,kp2) = phi(:,kp1)
 #pragma unroll
         for (int c = 0; c < C; c++) {
           row[c] = 0.0;
           pp[c] = 0.0;
         }
-        F.set(kp1, row, rcap);  // phi(:,kp1) = 0
+        F.set(kp1, row, any_hi);  // phi(:,kp1) = 0
       }
-      F.predict(k, S, pp, kcap);
+      SG_PROF(13);  // scale + shift
+      F.predict(k, S, pp, ncap, any_hi);
+      SG_PROF(14);  // predictor
       if (!(fl & FL_NORND)) {
 #pragma unroll
         for (int c = 0; c < C; c++) {
-          const double tau = h * pp[c] - F.r[15][c];
+          const double tau = h * pp[c] - F.r15[c];
           pp[c] = yy[c] + tau;
-          F.r[16][c] = (pp[c] - yy[c]) - tau;
+          F.r16[c] = (pp[c] - yy[c]) - tau;
         }
       } else {
 #pragma unroll
@@ -907,6 +1191,7 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
       seg = SEG_WAIT;
     }
 
+    SG_PROF(10);  // COEF tail
     if (RAYS_RARE(seg == SEG_STOP)) {
       done = 1;
       seg = SEG_WAIT;
@@ -928,6 +1213,7 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
       }
     }
 
+    SG_PROF(11);
     // ---- refill finished groups --------------------------------------------------------------------------------------
     if (__any(done)) {  // wave-uniform
       int nxt = 0;
@@ -943,6 +1229,26 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
       }
     }
   }
+  SG_PROF_FLUSH
+#ifndef RAYS_HOST_EMUL
+#undef gstr
+#endif
+#undef t
+#undef tout
+#undef absdel
+#undef tend
+#undef releps
+#undef abseps
+#undef sout
+#undef ds_ray
+#undef last_resid
+#undef prev_resid
+#undef maxr
+#undef rel_err
+#undef abs_err
+#undef hold
+#undef xold
+#undef round_
 }
 
 }  // namespace rays

@@ -84,6 +84,21 @@ RAYS_DEV const TraceArgs& cold_args(const TraceArgs&) {
 }
 #endif
 
+// The same for the parameter block (the kernels' first argument): re-derived where a phase of the trip starts, its
+// constants are loaded there (scalar loads the other waves of the SIMD hide) instead of being kept in -- and spilled
+// from -- scalar registers across the whole wave loop.  For the kernels built for several waves per SIMD.
+#ifdef RAYS_HOST_EMUL
+RAYS_DEV const DevParams& cold_params(const DevParams& P) { return P; }
+#else
+RAYS_DEV const DevParams& cold_params(const DevParams&) {
+  typedef const __attribute__((address_space(4))) char* kconst_ptr;
+  unsigned z;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+  kconst_ptr kb = (kconst_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  return *reinterpret_cast<const DevParams*>((const char*)(kb + z));
+}
+#endif
+
 // One recorded trajectory point, written by its own lane: ray_vec(:, pt) and residual(pt).
 template <int NV>
 RAYS_DEV void record_point(const TraceArgs& A, long long pt, const double v[NV], double resid) {

@@ -2,28 +2,55 @@
 // lane-group Shampine-Gordon kernel, rays_sg_group.hpp: one ray per group of G lanes, __shfl between them).
 // Included by hip_runtime.h when RAYS_EMUL_WAVE is defined.  Never part of librays_hip.so.
 //
-// Every lane is a fiber (ucontext) running the kernel function with its own threadIdx; a cross-lane operation
+// Every lane is a fiber (own stack, a few lines of assembly to switch) running the kernel function with its own threadIdx; a cross-lane operation
 // (__any, __ballot, __shfl) is a rendezvous: a lane deposits its operand and yields until every lane of the wave
 // that has not finished the kernel has arrived, then all read the operands.  This models the operations as the
 // hardware executes them when ALL lanes of the wave take part, which is how the kernels under test use them
 // (cross-lane operations sit in wave-uniform control flow); a lane that skips a rendezvous its wave-mates wait at
 // is reported as an error instead of dead-locking.  Lanes share the host thread's `rays::lds`, like a wave its LDS.
 #pragma once
-#include <ucontext.h>
-
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <vector>
 
+#if !defined(__x86_64__)
+#error "the host wave emulator switches fibers with a few lines of x86-64 assembly"
+#endif
+// Fiber switch: callee-saved registers + stack pointer (glibc's swapcontext also saves the signal mask -- a system
+// call per switch, and a rendezvous is 64 switches).
+extern "C" void rays_wave_emul_switch(void** save_sp, void* const* load_sp);
+asm(R"(
+.text
+.weak rays_wave_emul_switch
+.type rays_wave_emul_switch,@function
+rays_wave_emul_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq (%rsi), %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size rays_wave_emul_switch,.-rays_wave_emul_switch
+)");
+
 namespace wave_emul {
 constexpr int kLanes = 64;
 constexpr size_t kStackBytes = 1u << 20;
 
 struct Wave {
-  ucontext_t sched;
-  ucontext_t ctx[kLanes];
+  void* sched = nullptr;   // saved stack pointers
+  void* ctx[kLanes];
   std::vector<char> stacks;
   bool done[kLanes], waiting[kLanes];
   unsigned wait_epoch[kLanes];
@@ -52,7 +79,7 @@ inline const unsigned long long* exchange(unsigned long long v) {
   } else {
     w.waiting[me] = true;
     w.wait_epoch[me] = w.epoch;
-    swapcontext(&w.ctx[me], &w.sched);  // resumed by the scheduler once the epoch has moved on
+    rays_wave_emul_switch(&w.ctx[me], &w.sched);  // resumed by the scheduler once the epoch has moved on
   }
   return w.out;
 }
@@ -61,7 +88,8 @@ inline void lane_entry() {
   w.body();
   w.done[w.cur] = true;
   w.ndone++;
-  // (returns to the scheduler through uc_link)
+  rays_wave_emul_switch(&w.ctx[w.cur], &w.sched);  // never resumed
+  std::abort();
 }
 // run one wave: lanes base_thread .. base_thread + 63 of the current block
 inline void run_wave(unsigned base_thread, std::function<void()> body, emul_dim3& thread_idx) {
@@ -73,11 +101,15 @@ inline void run_wave(unsigned base_thread, std::function<void()> body, emul_dim3
   current() = &w;
   for (int i = 0; i < kLanes; i++) {
     w.done[i] = w.waiting[i] = false;
-    getcontext(&w.ctx[i]);
-    w.ctx[i].uc_stack.ss_sp = w.stacks.data() + kStackBytes * (size_t)i;
-    w.ctx[i].uc_stack.ss_size = kStackBytes;
-    w.ctx[i].uc_link = &w.sched;
-    makecontext(&w.ctx[i], (void (*)())lane_entry, 0);
+    // a fresh fiber: six zeroed callee-saved registers, then lane_entry as the address `ret` jumps to, on a stack
+    // that is 16-byte aligned at that point (so lane_entry starts as if it had been called)
+    char* top = w.stacks.data() + kStackBytes * (size_t)(i + 1);
+    top = (char*)((unsigned long long)top & ~15ull) - 64;
+    void** sp = (void**)top;
+    sp[0] = (void*)lane_entry;
+    sp[1] = nullptr;
+    for (int r = 1; r <= 6; r++) sp[-r] = nullptr;
+    w.ctx[i] = (void*)(sp - 6);
   }
   int idle_passes = 0;
   while (w.ndone < kLanes) {
@@ -90,7 +122,7 @@ inline void run_wave(unsigned base_thread, std::function<void()> body, emul_dim3
       }
       w.cur = i;
       thread_idx.x = base_thread + (unsigned)i;
-      swapcontext(&w.sched, &w.ctx[i]);
+      rays_wave_emul_switch(&w.sched, &w.ctx[i]);
       ran = true;
       // a lane that finished while others wait may have been the one they were waiting for
       if (w.arrived > 0 && w.arrived == kLanes - w.ndone) complete(w);

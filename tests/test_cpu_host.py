@@ -93,11 +93,11 @@ def test_c_abi_host_side_without_compute():
     for name in GOLDEN_CASES:
         g, nml, p = load_golden(name)
         hip.check_params(p)
-        assert hip.kernel_name(p).startswith(("rk4_trace_kernel<", "sg_trace_kernel<"))
+        assert hip.kernel_name(p).startswith(("rk4_trace_kernel<", "sg_trace_kernel<", "sg_group_kernel<"))
     # kernel selection: unit profile exponents -> EQ | 4 (no pow code), else the general kernels
     assert hip.kernel_name(load_golden("cfg2_solovev1024_rk4")[2]) == "rk4_trace_kernel<5, 2, 0, 7>"
     assert hip.kernel_name(load_golden("gold_solovev64_pow_rk4")[2]) == "rk4_trace_kernel<1, 2, 0, 7>"
-    assert hip.kernel_name(load_golden("gold_solovev64_sg_num")[2]) == "sg_trace_kernel<5, 2, 1, 7>"
+    assert hip.kernel_name(load_golden("gold_solovev64_sg_num")[2]) == "sg_group_kernel<5, 2, 4>"
     assert hip.kernel_name(load_golden("gold_axisym64_eqdsk_damp_rk4")[2]) == "rk4_trace_kernel<6, 2, 0, 8>"
     for code, text in STOP_FLAG_TEXT.items():
         assert hip.stop_flag_text(code) == text

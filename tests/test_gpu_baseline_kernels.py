@@ -134,14 +134,14 @@ def _tiled(r0, n0, nray):
 def test_sg_lane_refill_matches_oracle(which):
     """More rays than the SG kernels keep resident (65536 lanes): finished lanes pull new rays from the refill
     counter in the middle of other lanes' Adams steps.  163840 rays = 160 tiles of a 1024-ray fan, each tile
-    compared with the oracle's trace of that fan.  cfg3: `sg_trace_kernel<5, 2, 1, 7>` (Solovev, finite-
-    difference dD); cfg5: `sg_trace_kernel<6, 2, 0, 8>` (eqdsk splines + ECH damping)."""
+    compared with the oracle's trace of that fan.  cfg3: `sg_group_kernel<5, 2, 4>` (Solovev, finite-
+    difference dD: one ray per group of four lanes, 163840 rays on <= 98304 resident groups); cfg5: `sg_trace_kernel<6, 2, 0, 8>` (eqdsk splines + ECH damping)."""
     if which == "cfg3":
         p, r0, n0 = _fan("cfg3_solovev64k_sg_num.in", {
             "solovev_ray_init_nphi_ktheta_list": dict(n_rindex_theta=32, n_rindex_phi=32,
                                                       delta_rindex_theta=0.01, delta_rindex_phi=0.0125),
             "ode_list": dict(nstep_max=5)})
-        want = "sg_trace_kernel<5, 2, 1, 7>"
+        want = "sg_group_kernel<5, 2, 4>"
     else:
         g, nml0, p0 = load_golden("gold_axisym64_eqdsk_damp_sg")   # hands the eqdsk spline tables to hip + oracle
         tab = {k[4:]: (float(g[k]) if g[k].ndim == 0 else g[k]) for k in g.files if k.startswith("axi_")}
@@ -233,7 +233,7 @@ def test_per_step_parity_from_reference_points(name):
 
 
 @pytest.mark.parametrize("cfg,stride,kernel", [
-    ("cfg3_solovev64k_sg_num.in", 128, "sg_trace_kernel<5, 2, 1, 7>"),
+    ("cfg3_solovev64k_sg_num.in", 128, "sg_group_kernel<5, 2, 4>"),
     ("cfg5_axisym256k_sg_damp.in", 512, "sg_trace_kernel<6, 2, 0, 8>"),
     ("cfg5b_axisym256k_rk4_damp.in", 512, "rk4_trace_kernel<6, 2, 0, 8>")])
 def test_baseline_config_at_full_size_sampled_against_oracle(cfg, stride, kernel):
@@ -276,3 +276,24 @@ def test_trace_gather_device_resident_result():
     with pytest.raises(hip.RaysHipError, match="must not repeat a device"):
         hip.trace_gather(p, r0, n0)
     hip.load().rays_hip_init(1)
+
+
+@pytest.mark.parametrize("mapping,kernel", [("1", "sg_group_kernel<5, 2, 4>"), ("0", "sg_trace_kernel<5, 2, 1, 7>")])
+def test_sg_num_both_mappings_match_oracle(monkeypatch, mapping, kernel):
+    """SG + finite-difference dD (nv = 7) exists in two mappings: one ray per group of four lanes (rays_sg_group.hpp,
+    the default: deriv_num's central differences and the ODE components spread over the group) and one ray per lane
+    (rays_sg.hpp, RAYS_HIP_SG_GROUP=0).  3000 rays of the cfg 3 fan for twelve output intervals, incl. rays that
+    never start, against the oracle, bit for bit -- both.  (The full 64k fan of both against each other and the
+    oracle: tools/sg_group_check.py, profiles/r03/measurements/.)"""
+    monkeypatch.setenv("RAYS_HIP_SG_GROUP", mapping)
+    p, r0, n0 = _fan("cfg3_solovev64k_sg_num.in", {
+        "solovev_ray_init_nphi_ktheta_list": dict(n_rindex_theta=60, n_rindex_phi=50,
+                                                  delta_rindex_theta=0.32 / 60, delta_rindex_phi=0.4 / 50),
+        "ode_list": dict(nstep_max=12)})
+    assert hip.kernel_name(p, len(r0)) == kernel
+    r0, n0 = r0.copy(), n0.copy()
+    r0[7, 0] = 10.0      # outside the box
+    n0[11] *= 3.0        # stops at the initial check_save
+    out = hip.trace_host(p, r0, n0, ngpu=1)
+    ora = oracle_lib.trace(p, r0, n0, nthreads=os.cpu_count() or 1)
+    _assert_same(out, ora)
