@@ -523,7 +523,8 @@ def main():
                                 "valu_insts": c.get("valu_insts"), "clock_GHz": clk, "source": c.get("source"),
                                 "note": "issue_frac = FP64 wave-instructions x 4 clk / (1024 SIMDs x kernel time x clock): "
                                         "the share of all FP64 issue slots used; tflops counts add/mul/trans as 1 flop "
-                                        "and fma as 2 per lane (FMA contraction is off for bit-parity with the reference)"}
+                                        "and fma as 2 per lane (the exact kernels keep FMA contraction off for bit-parity with the "
+                                        "reference; the tolerance flavour lets the compiler fuse)"}
             except Exception as e:
                 print(f"[bench] profiles/counters.json unreadable: {e}", file=sys.stderr)
         idle = simd_idle_fraction(tr.npoints.cpu().numpy()) if world == 1 else None

@@ -32,7 +32,8 @@
     integer(c_int) :: which
     integer(c_int32_t), allocatable :: np32(:)
     character(len=512) :: msg
-    integer :: i
+    integer :: i, m, g
+    logical :: found
 
     select case (trim(profile_name))
        case ('Ptotal_psi'); which = RAYS_DEP_PTOTAL_PSI
@@ -47,11 +48,28 @@
     ! from the results file): v(8) = absorbed power fraction needs a run with damping (ode_m.f90:160-173)
     p%nv = size(ray_vec, 1)
     p%nstep_max = size(ray_vec, 2) - 1
-    if (p%nv /= 8 .and. p%nv /= 13) then
+    ! The binning reads v(1:3) and v(8) only; nv is the stride.  Any run with damping has the v(8) row:
+    ! nv = 8 [+ 1 + nspec with multi_spec_damping] [+ 5 with integrate_eq_gradients] (ode_m.f90:160-173).  A post-
+    ! processor has only the arrays, so the options are recovered from nv (where two combinations give the same nv
+    ! -- 13 = 8 + 5 = 8 + 1 + 4 species -- either describes the same rows 1..8).
+    if (p%nv < 8) then
        write(0,*) 'deposition_profile_hip: ray_vec carries no absorbed-power row (dim_v_vector =', p%nv, ')' ; stop 1
     end if
     p%damping_model = RAYS_DAMP_FUND_ECH
-    p%integrate_eq_gradients = merge(1, 0, p%nv == 13)
+    found = .false.
+    do m = 0, 1
+       do g = 0, 1
+          if (.not. found .and. 8 + m*(1 + p%nspec) + 5*g == p%nv) then
+             p%multi_spec_damping = m
+             p%integrate_eq_gradients = g
+             found = .true.
+          end if
+       end do
+    end do
+    if (.not. found) then
+       write(0,*) 'deposition_profile_hip: dim_v_vector =', p%nv, ' matches no combination of damping options for nspec =', p%nspec
+       stop 1
+    end if
 
     allocate(np32(number_of_rays))
     np32 = npoints

@@ -298,9 +298,12 @@ int rays_hip_scan_device(const rays_params_t* p, int n_runs, const double* d_ds_
  * sout = s + ds and, for SG_ODE, ray_stop%rel_err/abs_err at rel_err0/abs_err0 as after
  * ray_init_ode_solver, ode_m.f90:182-214) followed by the check_save trace_rays applies to the new point
  * (ray_tracing.f90:212-243).  d_v0[n][nv] states, d_s0[n] ray parameters (NULL = 0) -> d_v1[n][nv],
- * d_resid[n] (may be NULL), d_stop_code[n] (RAYS_STOP_NONE when the step was taken and kept; then v1 is
- * the new state; otherwise v1 = 0).  The states must satisfy the dispersion relation well enough to pass
- * check_save at v0, as any recorded trajectory point does.  Synchronises hip_stream. */
+ * d_resid[n] (may be NULL), d_stop_code[n]: RAYS_STOP_NONE when the step was taken and kept, then v1 is the new
+ * state.  Otherwise v1 is what ode_solver left in v: the advanced state when check_save refused the step
+ * (ray_tracing.f90:214-234), v0 when the solver itself stopped (RK4_ode_m.f90:83-89), zeros when v0 already failed
+ * the initial check_save (such a ray never starts: ray_tracing.f90:100-112) -- a recorded trajectory point always
+ * passes it.  Asynchronous on hip_stream like rays_hip_trace_device; its scratch (one block per device and stream)
+ * is kept between calls and released by rays_hip_finalize. */
 int rays_hip_ode_step_device(const rays_params_t* p, int n, const double* d_v0, const double* d_s0,
                              double* d_v1, double* d_resid, int32_t* d_stop_code, void* hip_stream);
 

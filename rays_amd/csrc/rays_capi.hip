@@ -458,6 +458,7 @@ int rays_hip_init_devices(int n, const int* device_ids) {
 
 static void release_cached_device_blocks();
 static void rccl_close_all();
+static void release_step_scratch();
 int rays_hip_finalize(void) {
   rccl_close_all();
   std::lock_guard<std::mutex> lk(g_mu);
@@ -481,6 +482,7 @@ int rays_hip_finalize(void) {
       (void)hipFree(kv.second.ptr);
     }
   g_sg_ws.clear();
+  release_step_scratch();
   release_cached_device_blocks();
   g_devices.clear();
   return 0;
@@ -679,17 +681,45 @@ int rays_hip_scan_device(const rays_params_t* p, int n_runs, const double* d_ds_
 namespace rays {
 __global__ void ode_step_collect_kernel(int n, int nv, const double* __restrict__ ray_vec,
                                         const double* __restrict__ residual, const int32_t* __restrict__ npoints,
-                                        const int32_t* __restrict__ stop, double* __restrict__ v1,
-                                        double* __restrict__ resid, int32_t* __restrict__ code) {
+                                        const int32_t* __restrict__ stop, const double* __restrict__ end_ray_vec,
+                                        double* __restrict__ v1, double* __restrict__ resid, int32_t* __restrict__ code) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   const bool stepped = npoints[r] == 2;  // the step was taken and passed check_save
-  for (int c = 0; c < nv; c++) v1[(long long)r * nv + c] = stepped ? ray_vec[((long long)r * 2 + 1) * nv + c] : 0.;
+  // not recorded: the state `ode_solver` left behind -- the advanced v when check_save refused the step, v0 when the
+  // solver itself stopped (ray_tracing.f90:214-234, RK4_ode_m.f90:83-89) -- is the trace kernels' end_ray_vec
+  // (zeros when v0 already failed the initial check_save: that ray never started, ray_tracing.f90:100-112)
+  for (int c = 0; c < nv; c++)
+    v1[(long long)r * nv + c] = stepped ? ray_vec[((long long)r * 2 + 1) * nv + c] : end_ray_vec[(long long)r * nv + c];
   if (resid) resid[r] = stepped ? residual[(long long)r * 2 + 1] : 0.;
   // a ray that took its one step ends on ' nstep > nstep_max' (or 'sout > s_max'), which is not a stop of this step
   code[r] = stepped ? RAYS_STOP_NONE : stop[r];
 }
 }  // namespace rays
+
+namespace {
+// scratch of rays_hip_ode_step_device, one block per (device, stream), grown on demand and kept (a host that calls
+// the entry per time step would otherwise pay four hipMalloc / hipFree per call); released by rays_hip_finalize
+std::map<std::pair<int, hipStream_t>, SgWorkspace> g_step_ws;
+int get_step_scratch(hipStream_t stream, size_t bytes, char** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mu);
+  SgWorkspace& w = g_step_ws[std::make_pair(dev, stream)];
+  if (w.bytes < bytes) {
+    if (w.ptr) {
+      HIP_TRY(hipStreamSynchronize(stream));
+      (void)hipFree(w.ptr);
+    }
+    w.ptr = nullptr;
+    w.bytes = 0;
+    HIP_TRY(hipMalloc(&w.ptr, bytes));
+    w.bytes = bytes;
+  }
+  *out = reinterpret_cast<char*>(w.ptr);
+  return 0;
+}
+}  // namespace
 
 int rays_hip_ode_step_device(const rays_params_t* p, int n, const double* d_v0, const double* d_s0,
                              double* d_v1, double* d_resid, int32_t* d_stop_code, void* hip_stream) {
@@ -702,30 +732,39 @@ int rays_hip_ode_step_device(const rays_params_t* p, int n, const double* d_v0, 
   rays_params_t q = *p;
   q.nstep_max = 1;
   q.s_max = 1.7976931348623157e308;
-  const size_t nv = (size_t)p->nv;
-  double *d_rv = nullptr, *d_res = nullptr;
-  int32_t *d_np = nullptr, *d_sc = nullptr;
-  auto release = [&]() { (void)hipFree(d_rv); (void)hipFree(d_res); (void)hipFree(d_np); (void)hipFree(d_sc); };
-  if (hipMalloc(&d_rv, sizeof(double) * 2 * nv * n) != hipSuccess || hipMalloc(&d_res, sizeof(double) * 2 * n) != hipSuccess ||
-      hipMalloc(&d_np, sizeof(int32_t) * n) != hipSuccess || hipMalloc(&d_sc, sizeof(int32_t) * n) != hipSuccess) {
-    release();
-    return fail("rays_hip_ode_step_device: out of device memory");
-  }
+  const size_t nv = (size_t)p->nv, N = (size_t)n;
+  // one block: ray_vec[n][2][nv] | residual[n][2] | end_ray_vec[n][nv] | npoints[n] | stop_code[n]
+  const size_t off_res = sizeof(double) * 2 * nv * N, off_ev = off_res + sizeof(double) * 2 * N,
+               off_np = off_ev + sizeof(double) * nv * N, off_sc = off_np + sizeof(int32_t) * N,
+               total = off_sc + sizeof(int32_t) * N;
+  char* base = nullptr;
+  rc = get_step_scratch(stream, total, &base);
+  if (rc) return rc;
+  double *d_rv = reinterpret_cast<double*>(base), *d_res = reinterpret_cast<double*>(base + off_res),
+         *d_ev = reinterpret_cast<double*>(base + off_ev);
+  int32_t *d_np = reinterpret_cast<int32_t*>(base + off_np), *d_sc = reinterpret_cast<int32_t*>(base + off_sc);
   TraceExtras x;
   x.v0 = d_v0;
   x.s0 = d_s0;
   // rvec0 / rindex_vec0 are not read when v0 is given; any valid pointer will do
-  rc = launch_trace(&q, n, d_v0, d_v0, d_rv, d_res, d_np, d_sc, nullptr, nullptr, nullptr, stream,
+  rc = launch_trace(&q, n, d_v0, d_v0, d_rv, d_res, d_np, d_sc, d_ev, nullptr, nullptr, stream,
                     RAYS_TRACE_NO_ZERO_FILL, x);
-  if (rc == 0) {
-    hipLaunchKernelGGL(rays::ode_step_collect_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, (int)nv, d_rv,
-                       d_res, d_np, d_sc, d_v1, d_resid, d_stop_code);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);  // the scratch arrays are released below
-    if (e != hipSuccess) rc = hip_fail(e, "rays_hip_ode_step_device");
-  }
-  release();
-  return rc;
+  if (rc) return rc;
+  hipLaunchKernelGGL(rays::ode_step_collect_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, (int)nv, d_rv,
+                     d_res, d_np, d_sc, d_ev, d_v1, d_resid, d_stop_code);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "rays_hip_ode_step_device");
+  return 0;  // asynchronous on `stream` like rays_hip_trace_device (the scratch block outlives the call)
+}
+
+static void release_step_scratch() {  // caller holds g_mu
+  for (auto& kv : g_step_ws)
+    if (kv.second.ptr) {
+      (void)hipSetDevice(kv.first.first);
+      (void)hipDeviceSynchronize();
+      (void)hipFree(kv.second.ptr);
+    }
+  g_step_ws.clear();
 }
 
 // Device buffers of rays_hip_trace are kept between calls (a host that traces repeatedly -- ray_scan, a

@@ -53,7 +53,12 @@ hipError_t launch_one(const DevParams& P, const TraceArgs& A, hipStream_t stream
   // (`if constexpr`: only the listed shapes get a two-waves-per-SIMD build compiled at all)
 #ifndef RAYS_HOST_EMUL
   if constexpr (OCC == 2) {
-    return launch_persistent(rk4_trace_kernel_w2<EQ, NS, DERIV, NV>, 0, P, A, stream, grid_blocks);
+#ifdef RAYS_RK4_W2_DIRECT_STORES
+    constexpr size_t lds2 = 0;
+#else
+    constexpr size_t lds2 = PointWindow<NV, true>::kLdsBytes;  // residual(:) only
+#endif
+    return launch_persistent(rk4_trace_kernel_w2<EQ, NS, DERIV, NV>, lds2, P, A, stream, grid_blocks);
   } else
 #endif
   {
@@ -66,7 +71,8 @@ hipError_t launch_one(const DevParams& P, const TraceArgs& A, hipStream_t stream
     return launch_persistent(rk4_trace_kernel<EQ, NS, DERIV, NV>, lds, P, A, stream, grid_blocks);
   }
 #else
-  constexpr size_t lds = (size_t)(kBlock / kWave) * SgLds<NV>::kDoublesPerWave * sizeof(double);
+  static_assert(kBlock / kWave == 4, "SgLds lays the block's four waves out");
+  constexpr size_t lds = SgLds<NV>::kLdsBytes;
   return launch_persistent(sg_trace_kernel<EQ, NS, DERIV, NV>, lds, P, A, stream, grid_blocks);
 #endif
 }

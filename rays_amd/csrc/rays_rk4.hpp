@@ -48,7 +48,11 @@ rk4_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
 template <int EQ, int NS, int DERIV, int NV>
 __global__ void __launch_bounds__(256, 2)
 rk4_trace_kernel_w2(const DevParams P_kernarg, const TraceArgs A_hot) {
+#ifdef RAYS_RK4_W2_DIRECT_STORES
 #define RAYS_RK4_USE_WINDOW 0
+#else
+#define RAYS_RK4_USE_WINDOW 2  // residual(:) through a 30 KB window, ray_vec stored directly (rays_trace.hpp)
+#endif
 #include "rays_rk4_body.inc"
 #undef RAYS_RK4_USE_WINDOW
 }

@@ -180,6 +180,10 @@ struct SgLds {  // LDS doubles per lane / per wave
   static constexpr int kPhiBase = SgCoef::kArrays * kSgTier;
   static constexpr int kPerLane = kPhiBase + sg_phi_lds_rows<NV>() * NV;
   static constexpr int kDoublesPerWave = kPerLane * kWave;
+  // gstr(0:13) as a 16-double table behind the four waves' columns, where the 160 KB leave room for it
+  static constexpr int kGstrBase = 4 * kDoublesPerWave;
+  static constexpr bool kGstrTable = (size_t)(kGstrBase + 16) * sizeof(double) <= 160 * 1024;
+  static constexpr size_t kLdsBytes = (size_t)(kGstrBase + (kGstrTable ? 16 : 0)) * sizeof(double);
 };
 
 // Divided differences phi(neqn,16) (ode_RAYS.f90:668), tiered as described above.
@@ -428,6 +432,18 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
   const int wave = threadIdx.x / kWave;
   constexpr int RR = sg_phi_reg_rows<NV>(), LR = sg_phi_lds_rows<NV>();
   const sg_lds_ptr lane_lds = (sg_lds_ptr)(lds + wave * SgLds<NV>::kDoublesPerWave + lane);
+#ifndef RAYS_HOST_EMUL
+  // gstr(1:13) is indexed by the lane's order: a lookup in a small LDS table (where the block's LDS has 128 bytes to
+  // spare) instead of the select chain over thirteen constants (~40 instructions a call, four calls per step)
+  if constexpr (SgLds<NV>::kGstrTable) {
+    if (threadIdx.x < 14) lds[SgLds<NV>::kGstrBase + threadIdx.x] = gstr((int)threadIdx.x);
+    __syncthreads();
+  }
+  const sg_lds_ptr gstr_tab = (sg_lds_ptr)(lds + SgLds<NV>::kGstrBase);
+#define RAYS_GSTR(i) (SgLds<NV>::kGstrTable ? (double)gstr_tab[(i)] : gstr(i))
+#else
+#define RAYS_GSTR(i) gstr(i)
+#endif
   SgCoef S;
   S.col = lane_lds;
   SgPhi<NV, RR, LR> F;  // divided differences phi(neqn,16)
@@ -655,10 +671,10 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
               erk = erk + q * q;
             }
             SG_PROF(17);
-            if (0 < km2) erkm2 = absh * S.sig(km1) * gstr(km2) * sqrt(erkm2);
-            if (0 <= km2) erkm1 = absh * S.sig(k) * gstr(km1) * sqrt(erkm1);
+            if (0 < km2) erkm2 = absh * S.sig(km1) * RAYS_GSTR(km2) * sqrt(erkm2);
+            if (0 <= km2) erkm1 = absh * S.sig(k) * RAYS_GSTR(km1) * sqrt(erkm1);
             const double err = absh * sqrt(erk) * (S.g(k) - S.g(kp1));
-            erk = absh * sqrt(erk) * S.sig(kp1) * gstr(k);
+            erk = absh * sqrt(erk) * S.sig(kp1) * RAYS_GSTR(k);
             knew = k;
             if (0 < km2) {
               if (fmax(erkm1, erkm2) <= erk) knew = km1;
@@ -743,7 +759,7 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
                 const double q = div(d2[l], wt[l]);
                 erkp1 = erkp1 + q * q;
               }
-              erkp1 = absh * gstr(kp1) * sqrt(erkp1);
+              erkp1 = absh * RAYS_GSTR(kp1) * sqrt(erkp1);
               if (k == 1) {
                 if (erkp1 < 0.5 * erk) {
                   k = kp1;
@@ -1077,6 +1093,7 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
     }
   }
   SG_PROF_FLUSH
+#undef RAYS_GSTR
 }
 
 }  // namespace rays

@@ -133,9 +133,12 @@ struct alignas(16) SectorPair { double a, b; };
 
 // NV = 7: both streams pass through the window.  NV = 8: a ray_vec record IS one sector (the slabs are
 // 64-byte aligned when the array is), so only residual(:) does.  Other NV: no window (kAny = false).
-template <int NV>
+// RES_ONLY (the two-waves-per-SIMD build, whose two blocks per CU cannot both hold the 156 KB window): residual(:)
+// alone goes through the window (30 KB) -- it is the stream that suffers most from partly written sectors, eight
+// bytes per step into a sector that is otherwise written back eight times -- and ray_vec is stored directly.
+template <int NV, bool RES_ONLY = false>
 struct PointWindow {
-  static constexpr bool kVec = NV == 7, kRes = NV == 7 || NV == 8, kAny = kRes;
+  static constexpr bool kVec = NV == 7 && !RES_ONLY, kRes = NV == 7 || NV == 8, kAny = kRes;
   static constexpr int kVecRows = kVec ? 63 : 0, kResRows = kRes ? 15 : 0;
   static constexpr int kStride = 256;  // lanes per block
   static constexpr size_t kLdsBytes = (size_t)(kVecRows + kResRows) * kStride * sizeof(double);

@@ -7,7 +7,10 @@
 set -e
 export RAYS_BENCH_SHARE_GPU=1 RAYS_BENCH_BACKEND=gloo
 run() { timeout -k 10 500 python bench.py --gpus 2 --steps 3 --warmup 1 "$@"; }
-run --verify-gather
+mkdir -p gpurun_out
+run --verify-gather | tee gpurun_out/rehearse_n2_gloo.txt
+# four ranks on the one card (the box allows six processes on it)
+timeout -k 10 700 python bench.py --gpus 4 --steps 2 --warmup 1 --verify-gather | tee gpurun_out/rehearse_n4_gloo.txt
 run --config $PWD/configs/cfg5b_axisym256k_rk4_damp.in --exchange deposition
 run --config $PWD/configs/cfg5b_axisym256k_rk4_damp.in --exchange deposition --exact-profile
 timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
