@@ -27,7 +27,7 @@ program ref_dump_driver
     use ray_init_m, only : nray, rvec0, rindex_vec0
     use ray_results_m, only : ray_vec, residual, npoints, ray_stop_flag, end_ray_vec, initial_ray_power, &
          & write_results_LD
-    use deposition_profiles_m, only : initialize_deposition_profiles, calculate_deposition_profiles, &
+    use deposition_profiles_m, only : write_deposition_profiles_LD, initialize_deposition_profiles, calculate_deposition_profiles, &
          & bin_a_ray, profiles_1D, n_profiles
     use equilibrium_m, only : equilibrium, eq_point, equilib_model
     use solovev_eq_m, only : rmaj, kappa, bphi0, iota0, outer_bound, psiB
@@ -208,6 +208,19 @@ program ref_dump_driver
        end do
        close(u2)
 #endif
+       ! RAYS_DUMP_DEPOSITION_LD: the reference's own list-directed profile file, deposition_profiles.<run_label>
+       ! (write_deposition_profiles_LD, deposition_profiles_m.f90:296-331) -- a data fixture for the writer of
+       ! rays_amd/results.py.  In the drop-in binary the profiles it prints are the GPU's.
+       call get_environment_variable('RAYS_DUMP_DEPOSITION_LD', sval, status=stat)
+       if (stat == 0 .and. len_trim(sval) > 0 .and. np_dump == n_profiles) then
+#ifdef RAYS_DROPIN
+          do ip = 1, n_profiles
+             profiles_1D(ip)%profile = hprofile(:, ip)
+             profiles_1D(ip)%Q_sum = hq(ip)
+          end do
+#endif
+          call write_deposition_profiles_LD
+       end if
     end if
 
     call get_environment_variable('RAYS_DUMP_AXISYM', sval, status=stat)

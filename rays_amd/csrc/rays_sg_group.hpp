@@ -48,7 +48,7 @@ struct GrpGeom {
   static constexpr int kBaseLane = NV % G, kBaseSlot = NV / G;  // who holds "pair 7", the unperturbed equilibrium
   static constexpr int kThreads = 256;  // the launch block (rays_launch.hpp: kBlock)
   static constexpr int kRaysPerBlock = kThreads / G;
-  static constexpr int kCoefLen = 14, kCoefArrays = 6, kScalars = 16;
+  static constexpr int kCoefLen = 13, kCoefArrays = 6, kScalars = 20, kInts = 8;
   static constexpr int kDoublesPerRay = kCoefArrays * kCoefLen + kScalars;
   static constexpr size_t kLdsBytes = 0;  // (dynamic LDS: none -- the coefficient columns are static arrays of the kernel)
 };
@@ -101,6 +101,11 @@ struct GCoef {
   // One LDS array per coefficient vector (distinct objects: the compiler then knows that a write of beta(i) cannot
   // change psi(i - 1) and does not wait for it), each [14][rays per block]; `a[x]` points at this ray's column.
   sg_lds_ptr a[kArrays];
+#ifdef RAYS_HOST_EMUL
+  int* ia;
+#else
+  __attribute__((address_space(3))) int* ia;  // the ray's column of integer scalars
+#endif
   int stride;
   struct Ref {
     sg_lds_ptr p;
@@ -120,8 +125,21 @@ struct GCoef {
   // Per-ray scalars of trace_rays / SG_ode / de that are touched once or twice per trip (or per interval): kept in
   // LDS, one column per ray, instead of in registers of every lane of the group.
   enum { T_ = 0, TOUT, ABSDEL, TEND, RELEPS, ABSEPS, SOUT, DS_RAY, LAST_RESID, PREV_RESID, MAXR, REL_ERR, ABS_ERR, HOLD,
-         XOLD, ROUND };
+         XOLD, ROUND, P5EPS, ABSH, ERK, ERKM1 };
   RAYS_DEV Ref sc(int i) const { return Ref{a[SC] + i * stride}; }
+  // ... and the integer ones of `step` / de that a trip touches once or twice
+  enum { NSTEP = 0, KOLD, NS_, KNEW, IFAIL, NOSTEP, KLE4 };
+  struct IRef {
+#ifdef RAYS_HOST_EMUL
+    int* p;
+#else
+    __attribute__((address_space(3))) int* p;
+#endif
+    RAYS_DEV operator int() const { return *p; }
+    RAYS_DEV const IRef& operator=(int x) const { *p = x; return *this; }
+    RAYS_DEV const IRef& operator=(const IRef& o) const { return *this = (int)o; }
+  };
+  RAYS_DEV IRef isc(int i) const { return IRef{ia + i * stride}; }
 };
 
 // This lane's rows of the divided differences phi(l, 1:16) for its C components.  Rows are indexed by the ray's
@@ -143,9 +161,11 @@ struct GPhi {
   static_assert(KR >= 2 && KR <= 12, "rows 1 and 2 are addressed directly");
   double lo[KR + 2][C];  // [1..KR]; [KR+1] is a zero pad for the unrolled restore loop
   double r15[C], r16[C];
-  double* far;           // this lane's workspace column
-  long long fstride;
-  RAYS_DEV double& hi(int q, int c) const { return far[((q - KR - 1) * C + c) * fstride]; }
+  const TraceArgs* args;  // the workspace column is re-derived where a row above the register tier is touched (rare):
+                          // two pointers less to carry through the wave loop
+  RAYS_DEV static long long fstride() { return (long long)gridDim.x * blockDim.x; }
+  RAYS_DEV double* far() const { return cold_args(*args).sg_far + ((long long)blockIdx.x * blockDim.x + threadIdx.x); }
+  RAYS_DEV double& hi(int q, int c) const { return far()[((q - KR - 1) * C + c) * fstride()]; }
   RAYS_DEV void clear() {
 #pragma unroll
     for (int q = 0; q < KR + 2; q++)
@@ -296,7 +316,7 @@ struct GPhi {
 };
 // doubles per lane of the launch's workspace (TraceArgs::sg_far) the lane-group kernel needs
 template <int G>
-constexpr int sg_group_far_doubles_per_lane() { return GPhi<GrpGeom<G>::CPL>::kFarDoubles; }
+constexpr int sg_group_far_doubles_per_lane() { return GPhi<GrpGeom<G>::CPL>::kFarDoubles + GrpGeom<G>::CPL; }  // + y of SG_ode
 
 // Equilibrium for determ at a (possibly perturbed) point; returns the equilibrium's stop code when check_box is set
 // (the group's base lane: equilibrium_m.f90:198-202, eqn_ray.f90:90-102).
@@ -529,14 +549,20 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
   // (the host wave emulator runs the lanes of a wave one after the other between cross-lane operations, not in
   // lock step: a column shared by the group's lanes would be read by one lane after another has updated it, so
   // there every lane keeps a copy of its own; the values are the same)
-  double coef_private[GCoef::kArrays][16];
+  double coef_private[GCoef::kArrays][20];
+  int icoef_private[8];
   for (int x = 0; x < GCoef::kArrays; x++) S.a[x] = coef_private[x];
+  S.ia = icoef_private;
   S.stride = 1;
   (void)lds;
 #else
   {
     constexpr int R = GEO::kRaysPerBlock;
-    __shared__ double s_psi[14 * R], s_alpha[14 * R], s_beta[14 * R], s_sig[14 * R], s_g[14 * R], s_v[14 * R], s_sc[16 * R];
+    // (13 entries each: psi, beta, v use 12, sig, g 13; intrp's w(1:13) in alpha -- its w(14) is never read, its
+    // loops end at ki + 1 - j <= 12)
+    __shared__ double s_psi[13 * R], s_alpha[13 * R], s_beta[13 * R], s_sig[13 * R], s_g[13 * R], s_v[13 * R], s_sc[20 * R];
+    __shared__ int s_isc[8 * R];
+    S.ia = (__attribute__((address_space(3))) int*)(s_isc + gib);
     S.a[GCoef::PSI] = (sg_lds_ptr)(s_psi + gib);
     S.a[GCoef::ALPHA] = (sg_lds_ptr)(s_alpha + gib);
     S.a[GCoef::BETA] = (sg_lds_ptr)(s_beta + gib);
@@ -557,8 +583,7 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
 #endif
   GPhi<C> F;
   F.clear();
-  F.fstride = (long long)gridDim.x * blockDim.x;
-  F.far = cold_args(A_hot).sg_far + ((long long)blockIdx.x * blockDim.x + threadIdx.x);
+  F.args = &A_hot;
   bool valid[C];  // this lane's slot holds an ODE component
 #pragma unroll
   for (int c = 0; c < C; c++) valid[c] = gl + G * c < NV;
@@ -574,11 +599,15 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
   bool alive = ray < A_hot.nray;
   bool need_init = alive;
   int pc = PC_CHECK;
-  int nstep = 0;
-  double yy[C], pp[C], ysave[C];  // (lane) y of `step`, the predicted p, y of SG_ode (the state `ode` last returned)
+  double yy[C], pp[C];  // (lane) y of `step`, the predicted p
+  // (y of SG_ode -- the state `ode` last returned, read when the ray stops -- lives behind the workspace rows)
+#define YSAVE(c) F.far()[(long long)(GPhi<C>::kFarDoubles + (c)) * GPhi<C>::fstride()]
   Recip wt[C];                    // (lane)
   double x = 0., h = 0., eps = 0.;
-  double p5eps = 0., absh = 0., erk = 0., erkm1 = 0.;
+#define p5eps S.sc(GCoef::P5EPS)
+#define absh S.sc(GCoef::ABSH)
+#define erk S.sc(GCoef::ERK)
+#define erkm1 S.sc(GCoef::ERKM1)
   // (t, tout, absdel, tend, releps, abseps, sout, ds_ray, the residual statistics, rel_err, abs_err, hold, xold, round:
   // in the ray's LDS column, GCoef::sc)
 #define t S.sc(GCoef::T_)
@@ -597,14 +626,28 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
 #define hold S.sc(GCoef::HOLD)
 #define xold S.sc(GCoef::XOLD)
 #define round_ S.sc(GCoef::ROUND)
-  int k = 1, kold = 0, ns = 0, knew = 1, ifail = 0, nostep = 0, kle4 = 0;
+  int k = 1;
+#define nstep S.isc(GCoef::NSTEP)
+#define kold S.isc(GCoef::KOLD)
+#define ns S.isc(GCoef::NS_)
+#define knew S.isc(GCoef::KNEW)
+#define ifail S.isc(GCoef::IFAIL)
+#define nostep S.isc(GCoef::NOSTEP)
+#define kle4 S.isc(GCoef::KLE4)
+  kold = 0;
+  ns = 0;
+  knew = 1;
+  ifail = 0;
+  nostep = 0;
+  kle4 = 0;
+  nstep = 0;
   int resume = SEG_WAIT;
   int waited = 0;
   int patience = kSgPatienceMax, probe = 0;
   unsigned fl = FL_START | FL_PHASE1 | FL_NORND | FL_FIRST;
 #pragma unroll
   for (int c = 0; c < C; c++) {
-    yy[c] = pp[c] = ysave[c] = 0.;
+    yy[c] = pp[c] = 0.;
     wt[c] = make_recip(1.0);
   }
 
@@ -623,7 +666,7 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
 #pragma unroll
         for (int l = 0; l < NV; l++)
           if (l == gl + G * c) yy[c] = v0[l];
-        ysave[c] = yy[c];
+        YSAVE(c) = yy[c];
       }
       pc = PC_CHECK;
       resume = SEG_WAIT;
@@ -920,7 +963,7 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
       rel_err = eps * releps;
       abs_err = eps * abseps;
 #pragma unroll
-      for (int c = 0; c < C; c++) ysave[c] = yy[c];  // y = yy
+      for (int c = 0; c < C; c++) YSAVE(c) = yy[c];  // y = yy
       t = x;
       const double total_error = fabs(rel_err) + fabs(abs_err);
       if (total_error > P.sg_error_limit) {
@@ -970,7 +1013,7 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
       if (RAYS_RARE(top && !finish && maxnum <= nostep)) {  // :536-548
         stop = (fl & FL_STIFF) ? RAYS_STOP_SG_STIFF : RAYS_STOP_SG_MAXNUM;
 #pragma unroll
-        for (int c = 0; c < C; c++) ysave[c] = yy[c];
+        for (int c = 0; c < C; c++) YSAVE(c) = yy[c];
         t = x;
         seg = SEG_STOP;
       }
@@ -997,7 +1040,7 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
 #pragma unroll
         for (int c = 0; c < C; c++) {
           yy[c] = yy[c] + hi * yout[c];
-          ysave[c] = yy[c];
+          YSAVE(c) = yy[c];
         }
         t = tout;
         pc = PC_CHECK;
@@ -1203,7 +1246,7 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
       if (A.end_ray_vec) {
 #pragma unroll
         for (int c = 0; c < C; c++)
-          if (valid[c]) A.end_ray_vec[(long long)ray * NV + gl + G * c] = ysave[c];
+          if (valid[c]) A.end_ray_vec[(long long)ray * NV + gl + G * c] = YSAVE(c);
       }
       if (gl == 0) {
         A.npoints[ray] = nstep + 1;
@@ -1249,6 +1292,18 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
 #undef hold
 #undef xold
 #undef round_
+#undef nstep
+#undef kold
+#undef ns
+#undef knew
+#undef ifail
+#undef nostep
+#undef kle4
+#undef p5eps
+#undef absh
+#undef erk
+#undef erkm1
+#undef YSAVE
 }
 
 }  // namespace rays

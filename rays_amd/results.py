@@ -136,6 +136,32 @@ def write_results_LD(path: str, r: RunResults) -> None:
         f.write("\n".join(lines) + "\n")
 
 
+def deposition_grid(grid_min: float, grid_max: float, n_bins: int) -> np.ndarray:
+    """grid(1:n_bins+1) of a deposition profile (deposition_profiles_m.f90:156-159, 198-201):
+    grid_min + delta*(i-1) with delta = (grid_max - grid_min)/real(n_bins)."""
+    delta = (float(grid_max) - float(grid_min)) / float(np.float32(n_bins))
+    return np.array([float(grid_min) + delta * i for i in range(n_bins + 1)])
+
+
+def write_deposition_profiles_LD(path: str, profiles: Sequence[Dict[str, Any]]) -> None:
+    """write_deposition_profiles_LD (post_process_lib/deposition_profiles_m.f90:296-331): the file
+    `deposition_profiles.<run_label>` that post_process_RAYS / graphics_RAYS read.  Per profile: a name record,
+    the profile, a grid-name record, the grid (n_bins + 1 edges), 'Ptotal_total_deposition' and Q_sum.
+    profiles: dicts with profile_name, grid_name (character(len=20) in the reference), profile[n_bins],
+    grid[n_bins+1] (deposition_grid), Q_sum -- e.g. the output of rays_hip_deposition."""
+    reals = lambda a: _records(ld_real(v) for v in np.asarray(a, dtype=np.float64).ravel())
+    lines: List[str] = []
+    for pr in profiles:
+        lines.append(" profile_name = " + str(pr["profile_name"])[:20].ljust(20))
+        lines += reals(pr["profile"])
+        lines.append(" grid_name = " + str(pr["grid_name"])[:20].ljust(20))
+        lines += reals(pr["grid"])
+        lines.append(" Ptotal_total_deposition")
+        lines += reals([pr["Q_sum"]])
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
 def _ld_values(tok: str) -> List[str]:
     """One list-directed token, with the r*c repeat form some compilers use."""
     if "*" in tok:

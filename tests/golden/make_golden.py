@@ -107,6 +107,7 @@ def check_deterministic(cfg):
 
 TABLES = os.path.join("configs", "solovev_65x65.geqdsk.tables.npz")
 LD_FIXTURE = os.path.join("tests", "golden", "run_results.gold_slab4_ld")
+DEP_LD_FIXTURE = os.path.join("tests", "golden", "deposition_profiles.gaxi")
 
 
 def results_file_fixture(out_root):
@@ -119,6 +120,21 @@ def results_file_fixture(out_root):
         subprocess.run([REF], cwd=d, env=env, check=True, stdout=subprocess.DEVNULL)
         shutil.copy(os.path.join(d, "run_results.ld4"), os.path.join(out_root, LD_FIXTURE))
     print("run_results.gold_slab4_ld")
+
+
+def deposition_file_fixture(out_root):
+    """tests/golden/deposition_profiles.gaxi: the reference post-processor's own list-directed profile file
+    (write_deposition_profiles_LD, deposition_profiles_m.f90:296-331) for configs/gold_axisym64_eqdsk_damp_rk4.in --
+    data for rays_amd/results.py: write_deposition_profiles_LD (SURVEY 8(f) f2 -> files)."""
+    with tempfile.TemporaryDirectory() as d:
+        shutil.copy(os.path.join(ROOT, "configs", "gold_axisym64_eqdsk_damp_rk4.in"), os.path.join(d, "rays.in"))
+        for f in os.listdir(os.path.join(ROOT, "configs")):
+            if f.endswith(".geqdsk"):
+                shutil.copy(os.path.join(ROOT, "configs", f), d)
+        env = dict(os.environ, RAYS_DUMP_FILE="dump.bin", RAYS_DUMP_DEPOSITION="dep.bin", RAYS_DUMP_DEPOSITION_LD="1")
+        subprocess.run([REF], cwd=d, env=env, check=True, stdout=subprocess.DEVNULL)
+        shutil.copy(os.path.join(d, "deposition_profiles.gaxi"), os.path.join(out_root, DEP_LD_FIXTURE))
+    print("deposition_profiles.gaxi")
 
 
 def same_bits(a, b):
@@ -146,6 +162,8 @@ def generate(out_root, only=()):
     os.makedirs(os.path.join(out_root, "configs"), exist_ok=True)
     if not only or "run_results.gold_slab4_ld" in only:
         results_file_fixture(out_root)
+    if not only or "deposition_profiles.gaxi" in only:
+        deposition_file_fixture(out_root)
     host_tabs = {}
     for name, cfg, subset, stride, nprobe in CASES:
         if only and name not in only:
@@ -260,6 +278,8 @@ def check():
         diffs += [f"{TABLES}: '{k}' differs" for k in sorted(set(a.files) & set(b.files)) if not same_bits(a[k], b[k])]
         if ld_records(os.path.join(d, LD_FIXTURE)) != ld_records(os.path.join(ROOT, LD_FIXTURE)):
             diffs.append(f"{LD_FIXTURE}: differs beyond its date / wall-time records")
+        if open(os.path.join(d, DEP_LD_FIXTURE)).read() != open(os.path.join(ROOT, DEP_LD_FIXTURE)).read():
+            diffs.append(f"{DEP_LD_FIXTURE}: differs")
     return diffs
 
 

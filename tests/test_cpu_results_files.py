@@ -221,3 +221,36 @@ def test_netcdf_file_structure_is_the_reference_writers(tmp_path):
     np.testing.assert_array_equal(nc["residual"], d["residual"][:, :npt])
     np.testing.assert_array_equal(nc["end_ray_vec"], d["end_ray_vec"].astype(np.float32))
     assert nc["ray_stop_flag"] == d["ray_stop_flag"]
+
+
+def test_deposition_profile_file_reproduces_the_reference_post_processors(tmp_path):
+    """rays_amd/results.py: write_deposition_profiles_LD against the reference post-processor's own
+    `deposition_profiles.<run_label>` for configs/gold_axisym64_eqdsk_damp_rk4.in (write_deposition_profiles_LD,
+    deposition_profiles_m.f90:296-331; tests/golden/deposition_profiles.gaxi, written by the reference binary):
+    profiles, Q_sum and bin edges from the fixture / the grid formula -> the same records and the same binary64 values."""
+    ref = os.path.join(ROOT, "tests", "golden", "deposition_profiles.gaxi")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "gold_axisym64_eqdsk_damp_rk4.npz"))
+    n_bins = int(g["dep_n_bins"])
+    names = [str(n).strip() for n in g["dep_names"]]
+    assert names == ["Ptotal_psi", "Ptotal_rho"]
+    profiles = [dict(profile_name=n, grid_name=n.split("_")[1], profile=g["dep_profile"][i], Q_sum=float(g["dep_q_sum"][i]),
+                     grid=R.deposition_grid(0.0, 1.0, n_bins)) for i, n in enumerate(names)]   # :176-177: psiN, rho in 0..1
+    out = tmp_path / "deposition_profiles.gaxi"
+    R.write_deposition_profiles_LD(str(out), profiles)
+    # same records, same number of values per record, every value the same binary64 (where a value needs all 17
+    # digits the compiler's runtime and ld_real may pick different ones of the strings that read back to it:
+    # .10119588148219836 / ...837 are the same double)
+    mine, theirs = out.read_text().split("\n"), open(ref).read().split("\n")
+    assert len(mine) == len(theirs)
+    for a, b in zip(mine, theirs):
+        if "=" in b or "Ptotal_total_deposition" in b:
+            assert a == b                          # name records: byte for byte (names padded to character(len=20))
+        else:
+            ta, tb = a.split(), b.split()
+            assert len(ta) == len(tb) and [float(x) for x in ta] == [float(x) for x in tb], (a, b)
+    # Q_sum is the ordered sum of the profile (deposition_profiles_m.f90:251)
+    for pr in profiles:
+        s = 0.0
+        for v in pr["profile"]:
+            s = s + float(v)
+        assert s == pr["Q_sum"]

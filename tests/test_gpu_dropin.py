@@ -65,11 +65,16 @@ def test_fortran_deposition_dropin_equals_reference_post_processor(cfg):
     against the reference's calculate_deposition_profiles on the reference run: work(n_bins, nray), the profiles
     and Q_sum of 'Ptotal_psi', 'Ptotal_rho' (eqdsk) / 'Ptotal_x' (slab), bit for bit."""
     from tests.refdump import read_deposition
-    outs = {}
+    outs, files = {}, {}
     for tag, binary in (("ref", REF), ("hip", HIPBIN)):
         with tempfile.TemporaryDirectory() as d:
-            _run(binary, cfg, d, extra_env={"RAYS_DUMP_DEPOSITION": "dep.bin"})
+            _run(binary, cfg, d, extra_env={"RAYS_DUMP_DEPOSITION": "dep.bin", "RAYS_DUMP_DEPOSITION_LD": "1"})
             outs[tag] = read_deposition(os.path.join(d, "dep.bin"))
+            # the profile file post_process_RAYS / graphics_RAYS read, written by the REFERENCE's own
+            # write_deposition_profiles_LD (deposition_profiles_m.f90:296-331) from the reference's sums / the GPU's
+            f = [x for x in os.listdir(d) if x.startswith("deposition_profiles.")]
+            files[tag] = open(os.path.join(d, f[0])).read() if f else None
+    assert files["hip"] == files["ref"]          # byte for byte (None for both where only one profile exists)
     assert outs["hip"]["names"] == outs["ref"]["names"] and len(outs["ref"]["names"]) >= 1
     for k in ("work", "profile"):
         for a, b in zip(outs["hip"][k], outs["ref"][k]):
