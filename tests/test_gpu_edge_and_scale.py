@@ -164,3 +164,29 @@ def test_pack_unpack_roundtrip_on_device():
     r = 7
     o, m = int(off[r]), int(npts[r])
     assert torch.equal(pv[o:o + m], tr.ray_vec[r, :m])
+
+
+def test_ode_step_returns_what_ode_solver_left_in_v():
+    """rays_hip_ode_step_device (the ode_m interface): for a step that check_save refuses, v1 is the ADVANCED state
+    (`call ode_solver` has updated v; trace_rays then does not record it: ray_tracing.f90:214-234) with the stop code
+    -- not zeros.  dispersion_resid_limit is set between the residual at the launch points (~1e-16) and the
+    residual one step on (~1e-12), so every ray passes its initial check and is refused after its first step; the
+    oracle's end_ray_vec of a one-step trace is that state."""
+    g, nml, p = load_golden("cfg2_solovev1024_rk4")
+    r0, n0 = g["rvec0_full"][:200], g["rindex_vec0_full"][:200]
+    q = copy_params(p)
+    q.nstep_max = 1
+    base = oracle_lib.trace(q, r0, n0)
+    assert (base["npoints"] == 2).all()
+    lim = float(np.sqrt(base["residual"][:, 1].min() * 1e-16))      # between the two
+    q.dispersion_resid_limit = lim
+    ora = oracle_lib.trace(q, r0, n0)
+    refused = (ora["npoints"] == 1) & (ora["stop_code"] == 40)      # 'dispersion_residual' after the step
+    assert refused.sum() > 100
+    v0 = base["ray_vec"][:, 0, :]
+    got, resid, code = hip.ode_step(q, v0)
+    np.testing.assert_array_equal(code, ora["stop_code"])
+    np.testing.assert_array_equal(got[refused], ora["end_ray_vec"][refused])
+    assert np.abs(got[refused] - v0[refused]).max() > 0             # advanced, not v0 and not zeros
+    taken = code == 0
+    np.testing.assert_array_equal(got[taken], base["ray_vec"][taken, 1, :])
