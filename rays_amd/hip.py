@@ -45,6 +45,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch bundles its own HIP runtime (libamdhip64.so.7, the SONAME of the system's too).  Whichever is loaded
+    # first serves the whole process; loaded in the other order -- this library (and with it /opt/rocm's runtime)
+    # first, torch afterwards -- the second runtime to initialise finds "no ROCm-capable device".  The Python host
+    # uses torch for device memory and streams (DeviceTrace, ode_step, bench.py), so torch goes first, always.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RaysHipError(
             f"{LIB_PATH} not found: build it with `make -C rays_amd/csrc` (needs hipcc, gfx950). "

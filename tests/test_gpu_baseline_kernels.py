@@ -297,3 +297,31 @@ def test_sg_num_both_mappings_match_oracle(monkeypatch, mapping, kernel):
     out = hip.trace_host(p, r0, n0, ngpu=1)
     ora = oracle_lib.trace(p, r0, n0, nthreads=os.cpu_count() or 1)
     _assert_same(out, ora)
+
+
+def test_sg_group_kernel_limits_and_scan():
+    """The lane-group SG kernel at the limits trace_rays tests on every trip (ray_tracing.f90:118-172): nstep_max = 0
+    (' nstep > nstep_max' before the first step), s_max inside the second interval ('sout > s_max'), and as the
+    kernel of a fused `ds` scan (every group reads its run's ds where its ray starts) -- against the oracle."""
+    from rays_amd.scan import RayScan, scan_values
+    g, nml, p = load_golden("gold_solovev64_sg_num")
+    r0, n0 = g["rvec0_full"][:40], g["rindex_vec0_full"][:40]
+    assert hip.kernel_name(p, len(r0)) == "sg_group_kernel<5, 2, 4>"
+    for change in (dict(nstep_max=0), dict(nstep_max=5, s_max=1.5 * float(p.ds)), dict(nstep_max=3)):
+        q = copy_params(p)
+        for k, v in change.items():
+            setattr(q, k, v)
+        out = hip.trace_host(q, r0, n0, ngpu=1)
+        ora = oracle_lib.trace(q, r0, n0)
+        _assert_same(out, ora)
+    q = copy_params(p)
+    q.nstep_max = 4
+    vals = scan_values("fixed_increment", 3, p_start=float(p.ds) * 0.5, p_incr=float(p.ds) * 0.5)
+    scan = RayScan(q, r0, n0, vals)
+    scan.launch()
+    for v, r in zip(vals, scan.results()):
+        qq = copy_params(q)
+        qq.ds = float(v)
+        ora = oracle_lib.trace(qq, r0, n0)
+        for k in ARRAYS:
+            np.testing.assert_array_equal(getattr(r, k), ora[k], err_msg=f"ds={v}: {k}")
