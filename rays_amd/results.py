@@ -286,6 +286,92 @@ def _write_netcdf_classic(path: str, dims, gatts, variables) -> None:
             f.write(blob)
 
 
+def _write_netcdf_classic_records(path: str, dims, numrecs: int, gatts, variables) -> None:
+    """A NetCDF classic (CDF-1) file whose variables are all RECORD variables over the unlimited dimension dims[0]
+    (size 0 in the header, `numrecs` records): the layout the netCDF library gives what the reference's
+    write_deposition_profiles_NC defines.  gatts: [(name, text | int array)]; variables: [(name, type, (dim names,
+    the record dimension first), array[numrecs, ...])].  Records are interleaved: record r of a variable starts at
+    its `begin` + r * (sum of all variables' per-record sizes, each padded to four bytes)."""
+    import struct
+
+    def pad4(b: bytes) -> bytes:
+        return b + b"\0" * (-len(b) % 4)
+
+    def nm(sname: str) -> bytes:
+        e = sname.encode()
+        return struct.pack(">I", len(e)) + pad4(e)
+
+    dim_index = {d[0]: i for i, d in enumerate(dims)}
+    sizes = dict(dims)
+    recs = []  # per variable: list of per-record blobs
+    for vname, typ, vdims, data in variables:
+        if not vdims or vdims[0] != dims[0][0]:
+            raise ValueError(f"{vname}: not a record variable")
+        code, dt, size = _NC_TYPE[typ]
+        arr = np.asarray(data).astype(dt) if typ != "char" else np.asarray(data, dtype="S1")
+        want = (numrecs,) + tuple(sizes[d] for d in vdims[1:])
+        arr = np.ascontiguousarray(arr).reshape(want)
+        recs.append([pad4(arr[r:r + 1].tobytes()) for r in range(numrecs)])   # (a slice keeps the big-endian dtype)
+    vsizes = [len(x[0]) if x else 0 for x in recs]
+    head = [b"CDF\x01", struct.pack(">I", numrecs), struct.pack(">II", 0x0A, len(dims))]
+    for i, (dname, size) in enumerate(dims):
+        head.append(nm(dname) + struct.pack(">I", 0 if i == 0 else size))
+    head.append(struct.pack(">II", 0x0C, len(gatts)) if gatts else struct.pack(">II", 0, 0))
+    for aname, val in gatts:
+        if isinstance(val, str):
+            e = val.encode()
+            head.append(nm(aname) + struct.pack(">II", 2, len(e)) + pad4(e))
+        else:
+            a = np.asarray(val).astype(">i4")
+            head.append(nm(aname) + struct.pack(">II", 4, a.size) + a.tobytes())
+    head.append(struct.pack(">II", 0x0B, len(variables)))
+    var_heads = []
+    for (vname, typ, vdims, _), vs in zip(variables, vsizes):
+        h = nm(vname) + struct.pack(">I", len(vdims)) + b"".join(struct.pack(">I", dim_index[d]) for d in vdims)
+        h += struct.pack(">II", 0, 0) + struct.pack(">I", _NC_TYPE[typ][0]) + struct.pack(">I", vs)
+        var_heads.append(h)
+    hlen = sum(len(x) for x in head) + sum(len(h) + 4 for h in var_heads)
+    begins, pos = [], hlen
+    for vs in vsizes:
+        begins.append(pos)
+        pos += vs
+    with open(path, "wb") as f:
+        f.write(b"".join(head))
+        for h, bg in zip(var_heads, begins):
+            f.write(h + struct.pack(">I", bg))
+        for r in range(numrecs):
+            for x in recs:
+                f.write(x[r])
+
+
+def write_deposition_profiles_NC(path: str, profiles: Sequence[Dict[str, Any]], run_label: str = "", date_vector=None) -> None:
+    """write_deposition_profiles_NC (post_process_lib/deposition_profiles_m.f90:336-420): `deposition_profiles.<label>.nc`
+    with the reference's dimensions (n_profiles UNLIMITED, n_bins, n_bins_p1, d20; :374-377), its eight variables in its
+    definition order and types (:380-387; Fortran dimension lists reversed into the file's C order) and its two global
+    attributes (RAYS_run_label, date_vector; :390-391).  profiles: as for write_deposition_profiles_LD, plus grid_min,
+    grid_max."""
+    n = len(profiles)
+    n_bins = len(np.asarray(profiles[0]["profile"])) if n else 0
+    if date_vector is None:
+        now = datetime.datetime.now().astimezone()
+        off = now.utcoffset()
+        date_vector = [now.year, now.month, now.day, int(off.total_seconds() // 60) if off else 0, now.hour, now.minute, now.second,
+                       now.microsecond // 1000]
+    P = "n_profiles"
+    dims = [(P, 0), ("n_bins", n_bins), ("n_bins_p1", n_bins + 1), ("d20", 20)]
+    name20 = lambda k: np.array([list(str(pr[k])[:20].ljust(20)) for pr in profiles], dtype="S1").reshape(n, 20)
+    variables = [("Q_sum", "double", (P,), [pr["Q_sum"] for pr in profiles]),
+                 ("n_bins", "int", (P,), [len(np.asarray(pr["profile"])) for pr in profiles]),
+                 ("grid_min", "double", (P,), [pr["grid_min"] for pr in profiles]),
+                 ("grid_max", "double", (P,), [pr["grid_max"] for pr in profiles]),
+                 ("profile_name", "char", (P, "d20"), name20("profile_name")),
+                 ("grid_name", "char", (P, "d20"), name20("grid_name")),
+                 ("grid", "double", (P, "n_bins_p1"), [pr["grid"] for pr in profiles]),
+                 ("profile", "double", (P, "n_bins"), [pr["profile"] for pr in profiles])]
+    _write_netcdf_classic_records(path, dims, n, [("RAYS_run_label", str(run_label)), ("date_vector", np.asarray(date_vector, dtype=np.int32))],
+                                  variables)
+
+
 def write_results_NC(path: str, r: RunResults) -> None:
     """write_results_NC (ray_results_m.f90:171-249): the same dimensions (:205-209) and variables (:212-224) in the
     same definition order with the same NetCDF types (ray_vec, residual double; the per-ray summaries NF90_FLOAT;

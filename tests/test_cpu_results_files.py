@@ -254,3 +254,66 @@ def test_deposition_profile_file_reproduces_the_reference_post_processors(tmp_pa
         for v in pr["profile"]:
             s = s + float(v)
         assert s == pr["Q_sum"]
+
+
+def test_deposition_profile_netcdf_file_has_the_reference_writers_structure(tmp_path):
+    """rays_amd/results.py: write_deposition_profiles_NC against the definitions of the reference's
+    write_deposition_profiles_NC (deposition_profiles_m.f90:374-391: n_profiles UNLIMITED, n_bins, n_bins_p1, d20;
+    Q_sum, n_bins, grid_min, grid_max, profile_name, grid_name, grid, profile in that order; RAYS_run_label and
+    date_vector as global attributes).  No NetCDF library in this image writes the reference's file, so the header is
+    parsed from the bytes (names, order, types, record dimension) and the values are read back with scipy."""
+    from scipy.io import netcdf_file
+    g = np.load(os.path.join(ROOT, "tests", "golden", "gold_axisym64_eqdsk_damp_rk4.npz"))
+    n_bins = int(g["dep_n_bins"])
+    names = [str(n).strip() for n in g["dep_names"]]
+    profiles = [dict(profile_name=n, grid_name=n.split("_")[1], profile=g["dep_profile"][i], Q_sum=float(g["dep_q_sum"][i]),
+                     grid=R.deposition_grid(0.0, 1.0, n_bins), grid_min=0.0, grid_max=1.0) for i, n in enumerate(names)]
+    out = str(tmp_path / "deposition_profiles.gaxi.nc")
+    R.write_deposition_profiles_NC(out, profiles, run_label="gaxi", date_vector=[2026, 10, 4, 0, 1, 2, 3, 4])
+    b = open(out, "rb").read()
+    assert b[:4] == b"CDF\x01" and struct.unpack(">I", b[4:8])[0] == 2            # two records = two profiles
+    pos = 8
+
+    def u32():
+        nonlocal pos
+        v = struct.unpack(">I", b[pos:pos + 4])[0]
+        pos += 4
+        return v
+
+    def name():
+        nonlocal pos
+        n = u32()
+        s = b[pos:pos + n].decode()
+        pos += n + (-n % 4)
+        return s
+
+    assert u32() == 0x0A
+    dims = [(name(), u32()) for _ in range(u32())]
+    assert dims == [("n_profiles", 0), ("n_bins", n_bins), ("n_bins_p1", n_bins + 1), ("d20", 20)]   # 0 = the record dimension
+    assert u32() == 0x0C
+    atts = []
+    for _ in range(u32()):
+        an, typ, cnt = name(), u32(), u32()
+        size = {2: 1, 4: 4}[typ] * cnt
+        atts.append((an, typ, cnt))
+        pos += size + (-size % 4)
+    assert atts == [("RAYS_run_label", 2, 4), ("date_vector", 4, 8)]
+    assert u32() == 0x0B
+    got = []
+    for _ in range(u32()):
+        vn = name()
+        vd = [u32() for _ in range(u32())]
+        assert u32() == 0 and u32() == 0            # no variable attributes
+        typ, vsize, begin = u32(), u32(), u32()
+        got.append((vn, typ, vd))
+    D, I, C_ = 6, 4, 2
+    assert got == [("Q_sum", D, [0]), ("n_bins", I, [0]), ("grid_min", D, [0]), ("grid_max", D, [0]),
+                   ("profile_name", C_, [0, 3]), ("grid_name", C_, [0, 3]), ("grid", D, [0, 2]), ("profile", D, [0, 1])]
+    with netcdf_file(out, "r", mmap=False) as f:
+        assert f.variables["profile"].isrec and f.dimensions["n_profiles"] is None
+        np.testing.assert_array_equal(np.array(f.variables["profile"].data), g["dep_profile"])
+        np.testing.assert_array_equal(np.array(f.variables["Q_sum"].data), g["dep_q_sum"])
+        np.testing.assert_array_equal(np.array(f.variables["grid"].data)[1], R.deposition_grid(0.0, 1.0, n_bins))
+        assert b"".join(np.array(f.variables["profile_name"].data)[1]).decode().strip() == "Ptotal_rho"
+        np.testing.assert_array_equal(np.array(f.variables["n_bins"].data), [n_bins, n_bins])
+        assert list(f.date_vector) == [2026, 10, 4, 0, 1, 2, 3, 4]
