@@ -4,6 +4,8 @@ in finalize_run, so that post_process_RAYS and graphics_RAYS consume a GPU run u
     write_results_LD  ->  run_results.<label>      list-directed text  (ray_results_m.f90:365-420)
     write_results_NC  ->  run_results.<label>.nc   NetCDF classic      (ray_results_m.f90:171-249)
     read_results_LD / read_results_NC              the matching readers (425-600 / 253-361)
+    write_deposition_profiles_LD / _NC  ->  deposition_profiles.<label>[.nc]   the post-processor's profile files
+                                            (post_process_lib/deposition_profiles_m.f90:296-331, 336-420)
 
 The text writer reproduces the record layout the reference's own build produces (flang
 list-directed output: one leading blank per record, records of at most 79 columns, a shortest
