@@ -195,17 +195,33 @@ struct PointWindow {
 #pragma unroll
     for (int i = 0; i < 7; i++) res[i * kStride] = res[(8 + i) * kStride];
   }
-  // the ray ended with n points: write what the window still holds
+  // the ray ended with n points: write what the window still holds.  Runs once per pass of the wave over its
+  // parked lanes (rays_rk4_body.inc), in chunks of eight rows: the LDS reads of a chunk are in flight together
+  // (element by element it was one LDS round trip per double, up to 56 of them per ray).
   RAYS_DEV void finish(const TraceArgs& A, long long pt0, int n, int pv, int pr) {
     const int K = n >> 3, m = n & 7;
     if constexpr (kVec) {
       double* g = A.ray_vec + pt0 * NV + (56 * K - pv);
+      const int u0 = K ? 0 : pv, u1 = pv + NV * m;  // u1 <= 7 + 49: rows 0..55, a chunk reads up to row 63
+      static_assert(kVecRows + kResRows >= 64, "finish reads whole chunks of eight rows");
 #pragma nounroll
-      for (int u = K ? 0 : pv; u < pv + NV * m; u++) g[u] = vec[u * kStride];
+      for (int b = u0 & ~7; b < u1; b += 8) {
+        double e[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) e[i] = vec[(b + i) * kStride];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+          if (b + i >= u0 && b + i < u1) g[b + i] = e[i];
+      }
     }
     double* gr = A.residual + pt0 + (8 * K - pr);
-#pragma nounroll
-    for (int u = K ? 0 : pr; u < pr + m; u++) gr[u] = res[u * kStride];
+    const int u0 = K ? 0 : pr, u1 = pr + m;  // u1 <= 14
+    double e[kResRows];
+#pragma unroll
+    for (int i = 0; i < kResRows; i++) e[i] = res[i * kStride];
+#pragma unroll
+    for (int i = 0; i < kResRows; i++)
+      if (i >= u0 && i < u1) gr[i] = e[i];
   }
 };
 

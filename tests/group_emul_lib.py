@@ -17,6 +17,7 @@ _LIB = os.path.join(_DIR, "librays_emul_group.so")
 _LIB_KR2 = os.path.join(_DIR, "librays_emul_group_kr2.so")
 _lib = None
 _lib_kr2 = None
+_variants = {}
 
 
 def build(out=None, defs=()):
@@ -34,7 +35,8 @@ def build(out=None, defs=()):
 def _build(defs):
     srcs = [os.path.join(_DIR, f) for f in ("emul_group.cpp", "emul_trace.cpp", "hip/hip_runtime.h", "hip/hip_wave_emul.h")]
     srcs += [os.path.join(_ROOT, "rays_amd", "csrc", f) for f in
-             ("rays_libm.hpp", "rays_device.hpp", "rays_trace.hpp", "rays_sg.hpp", "rays_sg_group.hpp", "rays_dev_params.inc")]
+             ("rays_libm.hpp", "rays_device.hpp", "rays_trace.hpp", "rays_sg.hpp", "rays_sg_group.hpp", "rays_dev_params.inc",
+              "rays_rk4.hpp", "rays_rk4_body.inc")]
     if os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs):
         return
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-extern-tls-init", "-fPIC",
@@ -46,7 +48,22 @@ def _load(path):
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
     l.rays_emul_trace_group.restype = C.c_int
     l.rays_emul_trace_group.argtypes = [C.POINTER(RaysParams), C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, ip, ip, dp, dp, dp]
+    l.rays_emul_trace_rk4_waves.restype = C.c_int
+    l.rays_emul_trace_rk4_waves.argtypes = [C.POINTER(RaysParams), C.c_int, C.c_int, dp, dp, dp, dp, ip, ip, dp, dp, dp]
+    l.rays_emul_set_zfun_table.restype = C.c_int
+    l.rays_emul_set_zfun_table.argtypes = [dp, C.c_int, C.c_double, C.c_double]
+    from tests.emul_lib import _set_zfun
+    _set_zfun(l.rays_emul_set_zfun_table)
     return l
+
+
+def lib_variant(tag: str, defs):
+    """The library compiled with extra -D switches (its own .so per tag)."""
+    if tag not in _variants:
+        path = os.path.join(_DIR, f"librays_emul_group_{tag}.so")
+        build(out=path, defs=list(defs))
+        _variants[tag] = _load(path)
+    return _variants[tag]
 
 
 def lib(small_tier=False):
@@ -62,9 +79,9 @@ def lib(small_tier=False):
     return _lib
 
 
-def set_axisym_tables(tab: dict):
+def set_axisym_tables(tab: dict, library=None):
     t, keep = axisym_tables_struct(tab)
-    fn = lib().rays_emul_set_axisym_tables
+    fn = (library or lib()).rays_emul_set_axisym_tables
     fn.restype = C.c_int
     fn.argtypes = [C.POINTER(AxisymTables), C.c_int, C.c_double, C.c_double]
     lin = "lin_psi" in tab
@@ -85,4 +102,24 @@ def trace(p: RaysParams, rvec0, rindex_vec0, G: int = 8, resident_blocks: int = 
                                      d(out["end_residuals"]), d(out["max_residuals"]))
     if rc:
         raise RuntimeError(f"rays_emul_trace_group rc={rc}")
+    return out
+
+
+def trace_rk4_waves(p: RaysParams, rvec0, rindex_vec0, nwaves: int = 1, library=None) -> dict:
+    """The one-ray-per-lane RK4 kernel on `nwaves` whole 64-lane waves (rays beyond 64 * nwaves are pulled by lanes
+    whose ray has ended)."""
+    rvec0 = np.ascontiguousarray(rvec0, dtype=np.float64)
+    rindex_vec0 = np.ascontiguousarray(rindex_vec0, dtype=np.float64)
+    nray, nv, npt = len(rvec0), p.nv, p.nstep_max + 1
+    out = dict(ray_vec=np.zeros((nray, npt, nv)), residual=np.zeros((nray, npt)),
+               npoints=np.zeros(nray, dtype=np.int32), stop_code=np.zeros(nray, dtype=np.int32),
+               end_ray_vec=np.zeros((nray, nv)), end_residuals=np.zeros(nray), max_residuals=np.zeros(nray))
+    d = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    rc = (library or lib()).rays_emul_trace_rk4_waves(C.byref(p), int(nwaves), nray, d(rvec0), d(rindex_vec0),
+                                                      d(out["ray_vec"]), d(out["residual"]), i(out["npoints"]),
+                                                      i(out["stop_code"]), d(out["end_ray_vec"]), d(out["end_residuals"]),
+                                                      d(out["max_residuals"]))
+    if rc:
+        raise RuntimeError(f"rays_emul_trace_rk4_waves rc={rc}")
     return out

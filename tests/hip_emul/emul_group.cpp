@@ -7,6 +7,18 @@
 #include "emul_trace.cpp"
 #include "../../rays_amd/csrc/rays_sg_group.hpp"
 
+static int attach_axisym_tables(const rays_params_t* p, rays::DevParams& D) {
+  if (p->equilib_model != RAYS_EQ_AXISYM) return 0;
+  if (p->axisym.magnetics_model == RAYS_AXI_MAG_EQDSK_SPLINE && (g_axi[2].empty() || g_axi_lin)) return 3;
+  if (p->axisym.magnetics_model == RAYS_AXI_MAG_EQDSK_LIN && (g_axi[2].empty() || !g_axi_lin)) return 3;
+  D.a_lin_dR = g_axi_dR; D.a_lin_dZ = g_axi_dZ;
+  D.a_nr = g_axi_n[0]; D.a_nz = g_axi_n[1]; D.a_n_rb = g_axi_n[2]; D.a_n_ne = g_axi_n[3]; D.a_n_te = g_axi_n[4]; D.a_n_ti = g_axi_n[5];
+  D.a_r_grid = g_axi[0].data(); D.a_z_grid = g_axi[1].data(); D.a_psi_fspl = g_axi[2].data();
+  D.a_rb_grid = g_axi[3].data(); D.a_rb_fspl = g_axi[4].data(); D.a_ne_grid = g_axi[5].data(); D.a_ne_fspl = g_axi[6].data();
+  D.a_te_grid = g_axi[7].data(); D.a_te_fspl = g_axi[8].data(); D.a_ti_grid = g_axi[9].data(); D.a_ti_fspl = g_axi[10].data();
+  return 0;
+}
+
 template <int EQ, int NS, int G>
 static int run_group(const rays::DevParams& D, const rays::TraceArgs& A, int resident_blocks) {
   typedef rays::GrpGeom<G> GEO;
@@ -45,19 +57,47 @@ extern "C" int rays_emul_trace_group(const rays_params_t* p, int G, int resident
   A.residual = residual; A.npoints = npoints; A.stop_code = stop_code; A.end_ray_vec = end_ray_vec;
   A.end_residuals = end_residuals; A.max_residuals = max_residuals; A.next_ray = &counter;
   rays::DevParams D = make_dev_params(*p);
-  if (p->equilib_model == RAYS_EQ_AXISYM) {
-    if (p->axisym.magnetics_model == RAYS_AXI_MAG_EQDSK_SPLINE && (g_axi[2].empty() || g_axi_lin)) return 3;
-    if (p->axisym.magnetics_model == RAYS_AXI_MAG_EQDSK_LIN && (g_axi[2].empty() || !g_axi_lin)) return 3;
-    D.a_lin_dR = g_axi_dR; D.a_lin_dZ = g_axi_dZ;
-    D.a_nr = g_axi_n[0]; D.a_nz = g_axi_n[1]; D.a_n_rb = g_axi_n[2]; D.a_n_ne = g_axi_n[3]; D.a_n_te = g_axi_n[4]; D.a_n_ti = g_axi_n[5];
-    D.a_r_grid = g_axi[0].data(); D.a_z_grid = g_axi[1].data(); D.a_psi_fspl = g_axi[2].data();
-    D.a_rb_grid = g_axi[3].data(); D.a_rb_fspl = g_axi[4].data(); D.a_ne_grid = g_axi[5].data(); D.a_ne_fspl = g_axi[6].data();
-    D.a_te_grid = g_axi[7].data(); D.a_te_fspl = g_axi[8].data(); D.a_ti_grid = g_axi[9].data(); D.a_ti_fspl = g_axi[10].data();
-  }
+  if (int rc = attach_axisym_tables(p, D)) return rc;
   const int e = p->equilib_model | (unit_exponents(*p) ? rays::kEqUnitExp : 0), ns = p->nspec + 1;
 #define RAYS_GRP_CASE(E, N) if (e == E && ns == N) return run_group_g<E, N>(G, D, A, resident_blocks);
   RAYS_GRP_CASE(0, 2) RAYS_GRP_CASE(4, 2) RAYS_GRP_CASE(0, 3) RAYS_GRP_CASE(4, 3)
   RAYS_GRP_CASE(1, 2) RAYS_GRP_CASE(5, 2) RAYS_GRP_CASE(2, 2) RAYS_GRP_CASE(6, 2)
 #undef RAYS_GRP_CASE
+  return 4;
+}
+
+// The one-ray-per-lane kernels on whole waves: `nwaves` blocks of one 64-lane wave each.  Fewer lanes than rays: lanes
+// whose ray has ended are parked, written out and refilled by the wave's batched pass (rays_rk4_body.inc) -- the
+// control flow a single emulated lane cannot exercise (its ballots have one bit).
+template <int EQ, int NS, int NV>
+static int run_rk4_waves(const rays::DevParams& D, const rays::TraceArgs& A, int nwaves) {
+  gridDim.x = (unsigned)nwaves;
+  blockDim.x = 64;
+  for (int b = 0; b < nwaves; b++) {
+    blockIdx.x = (unsigned)b;
+    wave_emul::run_wave(0u, [&] { rays::rk4_trace_kernel<EQ, NS, 0, NV>(D, A); }, threadIdx);
+  }
+  return 0;
+}
+extern "C" int rays_emul_trace_rk4_waves(const rays_params_t* p, int nwaves, int nray, const double* rvec0,
+                                         const double* rindex_vec0, double* ray_vec, double* residual, int32_t* npoints,
+                                         int32_t* stop_code, double* end_ray_vec, double* end_residuals, double* max_residuals) {
+  if (p->ode_solver != RAYS_ODE_RK4 || p->ray_deriv != RAYS_DERIV_COLD || p->multi_spec_damping || nwaves < 1) return 1;
+  unsigned counter = 0;
+  rays::TraceArgs A = rays::TraceArgs();
+  A.nray = nray; A.rvec0 = rvec0; A.rindex_vec0 = rindex_vec0; A.ray_vec = ray_vec;
+  A.residual = residual; A.npoints = npoints; A.stop_code = stop_code; A.end_ray_vec = end_ray_vec;
+  A.end_residuals = end_residuals; A.max_residuals = max_residuals; A.next_ray = &counter;
+  rays::DevParams D = make_dev_params(*p);
+  if (int rc = attach_axisym_tables(p, D)) return rc;
+  if (p->damping_model) {
+    if (g_zfun.empty()) return 2;
+    D.zf_fspl = g_zfun.data(); D.zf_nx = g_zf_nx; D.zf_xmin = g_zf_xmin; D.zf_xmax = g_zf_xmax;
+  }
+  const int e = p->equilib_model | (unit_exponents(*p) ? rays::kEqUnitExp : 0), ns = p->nspec + 1, nv = p->nv;
+#define RAYS_RK4W_CASE(E, N, V) if (e == E && ns == N && nv == V) return run_rk4_waves<E, N, V>(D, A, nwaves);
+  RAYS_RK4W_CASE(0, 2, 7) RAYS_RK4W_CASE(4, 2, 7) RAYS_RK4W_CASE(1, 2, 7) RAYS_RK4W_CASE(5, 2, 7)
+  RAYS_RK4W_CASE(2, 2, 8) RAYS_RK4W_CASE(6, 2, 8)
+#undef RAYS_RK4W_CASE
   return 4;
 }
