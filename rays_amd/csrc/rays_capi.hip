@@ -324,6 +324,39 @@ int get_sg_workspace(hipStream_t stream, size_t bytes, double** out) {
   return 0;
 }
 
+// State of the "long rays first" hand-out order of the RK4 kernels (TraceArgs::sched; rays_trace.hpp: take_rays), one
+// block per (device, stream) like the SG workspace.
+std::map<std::pair<int, hipStream_t>, SgWorkspace> g_sched_ws;
+int get_sched_workspace(hipStream_t stream, size_t bytes, unsigned int** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mu);
+  SgWorkspace& w = g_sched_ws[std::make_pair(dev, stream)];
+  if (w.bytes < bytes) {
+    if (w.ptr) {
+      HIP_TRY(hipStreamSynchronize(stream));
+      (void)hipFree(w.ptr);
+    }
+    w.ptr = nullptr;
+    w.bytes = 0;
+    HIP_TRY(hipMalloc(&w.ptr, bytes));
+    w.bytes = bytes;
+  }
+  *out = reinterpret_cast<unsigned int*>(w.ptr);
+  return 0;
+}
+// Neighbourhood size of that order: one ray in four is traced first.  RAYS_HIP_RAY_ORDER=index hands the
+// rays out in index order instead (for A/B measurements; the results are the same).
+// RAYS_HIP_RAY_ORDER=pilot2 ... pilot8: other neighbourhood sizes (developer switch).
+int sched_stride() {
+  const char* f = std::getenv("RAYS_HIP_RAY_ORDER");
+  if (!f || !f[0]) return 4;
+  if (f[0] == 'i') return 0;
+  const int n = (int)std::strlen(f);
+  const int s = f[n - 1] - '0';
+  return (s >= 2 && s <= 8) ? s : 4;
+}
+
 int counter_launched(int slot, hipStream_t stream) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
@@ -482,6 +515,13 @@ int rays_hip_finalize(void) {
       (void)hipFree(kv.second.ptr);
     }
   g_sg_ws.clear();
+  for (auto& kv : g_sched_ws)
+    if (kv.second.ptr) {
+      (void)hipSetDevice(kv.first.first);
+      (void)hipDeviceSynchronize();
+      (void)hipFree(kv.second.ptr);
+    }
+  g_sched_ws.clear();
   release_step_scratch();
   release_cached_device_blocks();
   g_devices.clear();
@@ -596,7 +636,24 @@ int launch_trace(const rays_params_t* p, int nray, const double* d_rvec0, const 
   A.rays_per_run = extra.rays_per_run;
   A.sg_far = nullptr;
   A.sg_far_lanes = 0;
+  A.sched = nullptr;
+  A.sched_stride = 0;
   const rays::KernelEntry* kernel = find_kernel(*p, nray);
+  const int stride = kernel->solver == RAYS_ODE_RK4 ? sched_stride() : 0;
+  if (stride > 1) {
+    // more rays than one wave per SIMD holds (the kernel decides with the lanes it is launched with)
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if ((long long)nray > (long long)rays::device_cu_count(dev) * rays::kBlock) {
+      const size_t words = 4 + rays::sched_pilots((unsigned)nray, stride);
+      unsigned int* ws = nullptr;
+      rc = get_sched_workspace(stream, sizeof(unsigned int) * words, &ws);
+      if (rc) return rc;
+      HIP_TRY(hipMemsetAsync(ws, 0, sizeof(unsigned int) * words, stream));
+      A.sched = ws;
+      A.sched_stride = stride;
+    }
+  }
   if (kernel->sg_far_per_lane > 0) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));

@@ -44,7 +44,96 @@ struct TraceArgs {
   // lane][sg_far_lanes]; the launcher never starts more lanes than sg_far_lanes
   double* __restrict__ sg_far;
   long long sg_far_lanes;
+  // RK4 kernels, fans of several rays per lane: hand-out order "long rays first" (take_rays below).  sched_stride = S
+  // > 1: sched = [sweep-1 cursor, sweep-2 cursor, 0, 0, state of the sched_pilots(nray, S) neighbourhoods], zeroed before
+  // the launch; 0: rays are handed out in index order by next_ray alone.
+  unsigned int* __restrict__ sched;
+  int sched_stride;
 };
+
+// ---- which ray a free lane traces next ---------------------------------------------------------------------------
+// With more rays than lanes the pass ends when the last ray does, so the rays handed out last should be the short
+// ones -- but a ray's length is only known once it has been traced.  Neighbouring rays of a fan are alike, though
+// (cfg 5b: standard deviation 3 steps within 64 consecutive rays, 28..54 between such blocks), so one ray in S is
+// traced first, as the PILOT of its neighbourhood (S - 1 rays close to it), and the others are handed out in two
+// sweeps over the neighbourhoods in index order: sweep 1 skips the neighbourhoods whose pilot has already ended (the
+// short ones) and hands out those whose pilot is still running (at that moment the longest rays there are); sweep 2
+// hands out what sweep 1 skipped.  tools/refill_model.py on cfg 5b's measured lengths: 773 trips in index order, 601-605
+// with this order, 589 with the rays sorted by their true lengths (ideal 518).  Every ray is handed out exactly
+// once: a pilot by the counter, a neighbour by whoever sets its bit in the neighbourhood's state word first.  The
+// order changes no ray's arithmetic.
+//
+// take_rays is called by ALL lanes of a wave from wave-uniform control flow (`want`: this lane needs a ray).  The
+// lanes that want one are served by ONE atomic of the wave per cursor and round (the first of them adds their number,
+// each takes base + its rank): a word of HBM-side atomics serves ~90 returning atomics per microsecond, and a fan
+// whose rays end together (cfg 4: 131072 lanes, eight times) otherwise queues a whole generation behind it.
+// Returns the lane's ray or -1 (none this time: ask again at the next pass); `dry` (wave-uniform) = no ray is left.
+constexpr unsigned kSchedDone = 0x80000000u;
+// Layout: the fan is cut into blocks of 64 S consecutive rays, S rows of 64; row 0 holds the block's 64 pilots, and
+// neighbourhood m = (block, column l) is column l of the block: its pilot and the S - 1 rays 64, 128, ... behind it.
+// So the 64 lanes of a wave hold 64 CONSECUTIVE rays whenever they ask together, as in index order (with pilots
+// S apart a wave's trajectories spread over S times the address range: the 1 M-ray fan ran 2-5 % slower).
+__host__ __device__ inline unsigned sched_pilots(unsigned nray, int S) { return (nray + 64u * (unsigned)S - 1u) / (64u * (unsigned)S) * 64u; }
+__host__ __device__ inline unsigned sched_pilot_ray(unsigned m, int S) { return (m >> 6) * 64u * (unsigned)S + (m & 63u); }
+__host__ __device__ inline bool sched_is_pilot(unsigned ray, int S) { return ((ray >> 6) % (unsigned)S) == 0u; }
+__host__ __device__ inline unsigned sched_neighbourhood(unsigned ray, int S) { return ray / (64u * (unsigned)S) * 64u + (ray & 63u); }
+RAYS_DEV unsigned wave_take(unsigned int* word, bool want, unsigned long long mask, int lane) {
+  // the lanes of `mask` get consecutive values of *word (the wave adds their number once)
+  const int n = __popcll(mask);
+  int leader = 0;
+  while (!((mask >> leader) & 1ull)) leader++;
+  unsigned base = 0;
+  if (want && lane == leader) base = atomicAdd(word, (unsigned)n);
+  base = (unsigned)__shfl((int)base, leader);
+  return base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+}
+RAYS_DEV int take_rays(const TraceArgs& A, unsigned total_lanes, int S, bool want, int lane, bool& dry) {
+  const unsigned nray = (unsigned)A.nray;
+  int got = -1;
+  dry = false;
+  unsigned long long mask = __ballot(want);
+  if (!mask) return got;
+  if (S <= 1) {  // index order
+    const unsigned nxt = wave_take(A.next_ray, want, mask, lane) + total_lanes;
+    if (want && nxt < nray) got = (int)nxt;
+    dry = __any(want && got < 0);  // the counter is past the last ray
+    return got;
+  }
+  const unsigned M = sched_pilots(nray, S);                   // neighbourhoods = pilots
+  const unsigned first = total_lanes < M ? total_lanes : M;   // pilots the lanes started with
+  if (first < M) {
+    const unsigned p = wave_take(A.next_ray, want, mask, lane) + first;
+    if (want && p < M && sched_pilot_ray(p, S) < nray) got = (int)sched_pilot_ray(p, S);
+    mask = __ballot(want && got < 0);
+    if (!mask) return got;
+  }
+  unsigned int* state = A.sched + 4;
+  const unsigned W = (unsigned)S - 1u, Q = M * W;  // neighbour slots
+  int rounds = 6;
+  for (int sweep = 0; sweep < 2; sweep++) {
+    for (;;) {
+      if (--rounds < 0) return got;
+      const bool w = want && got < 0;
+      const unsigned q = wave_take(A.sched + sweep, w, mask, lane);
+      if (w && q < Q) {
+        // consecutive slots are consecutive rays: slot -> (block of 64 S rays, row k = 1..S-1 of it, column l)
+        const unsigned blk = q >> 6, l = q & 63u, B = blk / W, k = blk - B * W + 1u;
+        const unsigned m = (B << 6) + l, r = ((B * (unsigned)S + k) << 6) + l;
+        // sweep 1 leaves the neighbourhoods whose pilot has ended (the short ones) to sweep 2
+        if (r < nray && !(sweep == 0 && (*(volatile unsigned int*)(state + m) & kSchedDone))) {
+          const unsigned old = atomicOr(state + m, 1u << k);
+          if (!(old & (1u << k))) got = (int)r;
+        }
+      }
+      const bool past = __any(w && q >= Q);  // this cursor has run off its end
+      mask = __ballot(want && got < 0);
+      if (!mask) return got;
+      if (past) break;
+    }
+  }
+  dry = true;  // both sweeps are through and lanes still want: nothing is left
+  return got;
+}
 
 // Start of a ray: initialize_ode_vector (or the caller's v0), the ray parameter and the run's step.
 template <int EQ, int NS, int NV>

@@ -49,7 +49,7 @@ def _load(path):
     l.rays_emul_trace_group.restype = C.c_int
     l.rays_emul_trace_group.argtypes = [C.POINTER(RaysParams), C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, ip, ip, dp, dp, dp]
     l.rays_emul_trace_rk4_waves.restype = C.c_int
-    l.rays_emul_trace_rk4_waves.argtypes = [C.POINTER(RaysParams), C.c_int, C.c_int, dp, dp, dp, dp, ip, ip, dp, dp, dp]
+    l.rays_emul_trace_rk4_waves.argtypes = [C.POINTER(RaysParams), C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, ip, ip, dp, dp, dp]
     l.rays_emul_set_zfun_table.restype = C.c_int
     l.rays_emul_set_zfun_table.argtypes = [dp, C.c_int, C.c_double, C.c_double]
     from tests.emul_lib import _set_zfun
@@ -105,9 +105,9 @@ def trace(p: RaysParams, rvec0, rindex_vec0, G: int = 8, resident_blocks: int = 
     return out
 
 
-def trace_rk4_waves(p: RaysParams, rvec0, rindex_vec0, nwaves: int = 1, library=None) -> dict:
+def trace_rk4_waves(p: RaysParams, rvec0, rindex_vec0, nwaves: int = 1, library=None, stride: int = 0) -> dict:
     """The one-ray-per-lane RK4 kernel on `nwaves` whole 64-lane waves (rays beyond 64 * nwaves are pulled by lanes
-    whose ray has ended)."""
+    whose ray has ended; stride > 1: in the "long rays first" order of rays_trace.hpp: take_rays)."""
     rvec0 = np.ascontiguousarray(rvec0, dtype=np.float64)
     rindex_vec0 = np.ascontiguousarray(rindex_vec0, dtype=np.float64)
     nray, nv, npt = len(rvec0), p.nv, p.nstep_max + 1
@@ -116,7 +116,7 @@ def trace_rk4_waves(p: RaysParams, rvec0, rindex_vec0, nwaves: int = 1, library=
                end_ray_vec=np.zeros((nray, nv)), end_residuals=np.zeros(nray), max_residuals=np.zeros(nray))
     d = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
     i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
-    rc = (library or lib()).rays_emul_trace_rk4_waves(C.byref(p), int(nwaves), nray, d(rvec0), d(rindex_vec0),
+    rc = (library or lib()).rays_emul_trace_rk4_waves(C.byref(p), int(nwaves), int(stride), nray, d(rvec0), d(rindex_vec0),
                                                       d(out["ray_vec"]), d(out["residual"]), i(out["npoints"]),
                                                       i(out["stop_code"]), d(out["end_ray_vec"]), d(out["end_residuals"]),
                                                       d(out["max_residuals"]))

@@ -79,7 +79,8 @@ static int run_rk4_waves(const rays::DevParams& D, const rays::TraceArgs& A, int
   }
   return 0;
 }
-extern "C" int rays_emul_trace_rk4_waves(const rays_params_t* p, int nwaves, int nray, const double* rvec0,
+// stride > 1: the "long rays first" hand-out order (rays_trace.hpp: take_rays) with that neighbourhood size
+extern "C" int rays_emul_trace_rk4_waves(const rays_params_t* p, int nwaves, int stride, int nray, const double* rvec0,
                                          const double* rindex_vec0, double* ray_vec, double* residual, int32_t* npoints,
                                          int32_t* stop_code, double* end_ray_vec, double* end_residuals, double* max_residuals) {
   if (p->ode_solver != RAYS_ODE_RK4 || p->ray_deriv != RAYS_DERIV_COLD || p->multi_spec_damping || nwaves < 1) return 1;
@@ -88,6 +89,12 @@ extern "C" int rays_emul_trace_rk4_waves(const rays_params_t* p, int nwaves, int
   A.nray = nray; A.rvec0 = rvec0; A.rindex_vec0 = rindex_vec0; A.ray_vec = ray_vec;
   A.residual = residual; A.npoints = npoints; A.stop_code = stop_code; A.end_ray_vec = end_ray_vec;
   A.end_residuals = end_residuals; A.max_residuals = max_residuals; A.next_ray = &counter;
+  std::vector<unsigned> sched;
+  if (stride > 1) {
+    sched.assign(4 + (size_t)rays::sched_pilots((unsigned)nray, stride), 0u);
+    A.sched = sched.data();
+    A.sched_stride = stride;
+  }
   rays::DevParams D = make_dev_params(*p);
   if (int rc = attach_axisym_tables(p, D)) return rc;
   if (p->damping_model) {

@@ -28,12 +28,14 @@ extern thread_local emul_dim3 threadIdx, blockIdx, blockDim, gridDim;
 #else
 inline int __any(int x) { return x; }
 inline unsigned long long __ballot(int x) { return x ? 1ull : 0ull; }
+inline int __shfl(int x, int, int = 64) { return x; }  /* only lane 0 exists */
 #endif
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 #define __builtin_amdgcn_readlane(v, r) ((r) == 0 ? (v) : 0)  /* only lane 0 exists */
 #define __builtin_amdgcn_wave_barrier() ((void)0)
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
 using std::copysign; using std::fabs; using std::fmax; using std::fmin; using std::ilogb;
 using std::pow; using std::scalbn; using std::sqrt; using std::exp;
 #ifdef RAYS_EMUL_RUNTIME

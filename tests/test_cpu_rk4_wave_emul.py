@@ -30,16 +30,19 @@ def _check(out, ora):
         np.testing.assert_array_equal(out[k], ora[k], err_msg=k)
 
 
+@pytest.mark.parametrize("stride", [0, 4, 3, 16])
 @pytest.mark.parametrize("variant", list(VARIANTS))
-def test_solovev_fan_with_refills(variant):
+def test_solovev_fan_with_refills(variant, stride):
     """200 rays of the Solovev fan at their natural, ragged lengths (99..380 steps) on ONE wave: every lane is
-    refilled two or three times, rays end on different trips, the last pass finds the counter dry."""
+    refilled two or three times, rays end on different trips, the last pass finds the counter dry.  stride > 1: the rays
+    are handed out "long rays first" (rays_trace.hpp: take_rays -- pilots, then two sweeps over their neighbourhoods; with
+    stride 16 there are fewer pilots than lanes and most lanes start in the first sweep), every ray exactly once."""
     g, nml, p = load_golden("cfg2_solovev1024_rk4")
     r0, n0 = g["rvec0_full"][::5][:200].copy(), g["rindex_vec0_full"][::5][:200].copy()
     n0[7] *= 3.0   # far off the dispersion surface: stops at its initial check
     ora = oracle_lib.trace(p, r0, n0)
     assert len(set(ora["npoints"].tolist())) > 20 and ora["npoints"][7] == 1
-    _check(ge.trace_rk4_waves(p, r0, n0, nwaves=1, library=_lib(variant)), ora)
+    _check(ge.trace_rk4_waves(p, r0, n0, nwaves=1, library=_lib(variant), stride=stride), ora)
 
 
 @pytest.mark.parametrize("variant", ["default", "cost0"])
@@ -63,6 +66,7 @@ def test_slab_box_exits_two_waves(variant):
     ora = oracle_lib.trace(p, r0, n0)
     assert len(set(ora["stop_code"].tolist())) > 1
     _check(ge.trace_rk4_waves(p, r0, n0, nwaves=2, library=_lib(variant)), ora)
+    _check(ge.trace_rk4_waves(p, r0, n0, nwaves=2, library=_lib(variant), stride=4), ora)
 
 
 def test_eqdsk_damping_fan_with_refills():
@@ -74,4 +78,6 @@ def test_eqdsk_damping_fan_with_refills():
     r0, n0 = np.tile(g["rvec0_full"], (reps, 1))[:150], np.tile(g["rindex_vec0_full"], (reps, 1))[:150]
     q = copy_params(p)
     q.nstep_max = min(q.nstep_max, 60)
-    _check(ge.trace_rk4_waves(q, r0, n0, nwaves=1, library=library), oracle_lib.trace(q, r0, n0))
+    ora = oracle_lib.trace(q, r0, n0)
+    _check(ge.trace_rk4_waves(q, r0, n0, nwaves=1, library=library), ora)
+    _check(ge.trace_rk4_waves(q, r0, n0, nwaves=1, library=library, stride=4), ora)

@@ -259,6 +259,44 @@ def test_baseline_config_at_full_size_sampled_against_oracle(cfg, stride, kernel
     assert np.isfinite(a.ray_vec[live]).all()
 
 
+@pytest.mark.parametrize("cfg,overrides", [
+    ("cfg5b_axisym256k_rk4_damp.in", {}),
+    ("cfg3b_solovev64k_rk4.in", {"solovev_ray_init_nphi_ktheta_list": dict(n_rindex_theta=300, n_rindex_phi=333,
+                                                                       delta_rindex_theta=0.32 / 300,
+                                                                       delta_rindex_phi=0.4 / 333),
+                                 "ray_init_list": dict(nray_max=300 * 333), "ode_list": dict(nstep_max=300)})])
+def test_ray_hand_out_order_changes_nothing(monkeypatch, cfg, overrides):
+    """Fans of more rays than lanes: the RK4 kernels hand the rays out "long rays first" (pilots, then two sweeps over
+    their neighbourhoods: rays_trace.hpp take_rays).  A scheduling property, so it is checked as one: every ray is
+    traced (npoints >= 1 everywhere -- a ray handed out to nobody would keep 0), and the complete result arrays are
+    the same bits for index order and for neighbourhoods of 2, 4 (the default) and 8 rays -- incl. a fan whose size
+    (99900) is no multiple of the block of 64 x 4 rays.  The oracle comparison of the same kernels at these sizes is
+    test_baseline_config_at_full_size_sampled_against_oracle / the w2 tests above."""
+    import torch
+    from rays_amd.trace import DeviceTrace
+    tab = None
+    if "axisym" in cfg:
+        g, _, _ = load_golden("gold_axisym64_eqdsk_damp_sg")
+        tab = {k[4:]: (float(g[k]) if g[k].ndim == 0 else g[k]) for k in g.files if k.startswith("axi_")}
+    p, r0, n0 = _fan(cfg, overrides, tables=tab)
+    assert len(r0) > 65536 and "w2" not in hip.kernel_name(p, len(r0))   # more rays than the 65536 lanes of the launch
+    ref = None
+    for order in ("index", "pilot", "pilot2", "pilot8"):
+        monkeypatch.setenv("RAYS_HIP_RAY_ORDER", order)
+        tr = DeviceTrace(p, r0, n0)
+        tr.launch()
+        torch.cuda.synchronize()
+        assert int(tr.npoints.min()) >= 1, order
+        got = {k: getattr(tr, k) for k in ARRAYS}
+        if ref is None:
+            ref = got
+        else:
+            for k in ARRAYS:
+                assert torch.equal(got[k].view(torch.int64) if got[k].dtype == torch.float64 else got[k],
+                                   ref[k].view(torch.int64) if ref[k].dtype == torch.float64 else ref[k]), (order, k)
+        del tr
+
+
 def test_trace_gather_device_resident_result():
     """rays_hip_trace_gather: the library's own multi-GPU entry (blocks per device, RCCL gather to the root, result
     left in device memory).  On the one-GPU box it runs with one device: the root traces into the global arrays and

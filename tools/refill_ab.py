@@ -17,8 +17,9 @@ for cfg, scale, nstep, reps in CASES:
     if not os.path.exists(cfg):
         print("missing", cfg); continue
     nml, p, r0, n0 = bench.build_fan(cfg, 1, scale, nstep)
-    for flavour in ("exact", "tolerance"):
+    for flavour, order in (("exact", "index"), ("exact", "pilot"), ("tolerance", "index"), ("tolerance", "pilot")):
         hip.set_numerics(flavour)
+        os.environ["RAYS_HIP_RAY_ORDER"] = order  # read by the library at every launch (rays_capi.hip: sched_enabled)
         dt = DeviceTrace(p, r0, n0)
         dt.launch(); torch.cuda.synchronize()
         ts = []
@@ -31,9 +32,9 @@ for cfg, scale, nstep, reps in CASES:
         # every 997th ray's trajectory
         sample = dt.ray_vec[::997].cpu().numpy()
         crc2 = zlib.crc32(sample.tobytes())
-        print(f"{os.path.basename(cfg)} x{scale} {flavour:9s} nray={len(n)} steps={st} best {min(ts):.3f} mean {np.mean(ts):.3f} ms  "
+        print(f"{os.path.basename(cfg)} x{scale} {flavour:9s} {order:5s} nray={len(n)} steps={st} best {min(ts):.3f} mean {np.mean(ts):.3f} ms  "
               f"{hip.kernel_name(p, len(n))}  counts {crc:08x} traj {crc2:08x}", flush=True)
         del dt
-        if hip.kernel_name(p, len(n)).startswith("sg_"):
+        if hip.kernel_name(p, len(n)).startswith("sg_") and order == "pilot":
             break
 hip.set_numerics("exact")
