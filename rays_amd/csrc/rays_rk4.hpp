@@ -36,7 +36,9 @@ rk4_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
 #else
 #define RAYS_RK4_USE_WINDOW 1
 #endif
+#define RAYS_RK4_LONG_FIRST 1  // pass loop around the trip loop, rays handed out long-first (rays_rk4_body.inc)
 #include "rays_rk4_body.inc"
+#undef RAYS_RK4_LONG_FIRST
 #undef RAYS_RK4_USE_WINDOW
 }
 
@@ -53,10 +55,21 @@ rk4_trace_kernel_w2(const DevParams P_kernarg, const TraceArgs A_hot) {
 #else
 #define RAYS_RK4_USE_WINDOW 2  // residual(:) through a 30 KB window, ray_vec stored directly (rays_trace.hpp)
 #endif
+#define RAYS_RK4_LONG_FIRST 0  // one loop, rays in index order: what fits this build's 256 registers (rays_rk4_body.inc)
 #include "rays_rk4_body.inc"
+#undef RAYS_RK4_LONG_FIRST
 #undef RAYS_RK4_USE_WINDOW
 }
 #else
+// (host emulation: the same two bodies, for the CPU test tier)
+template <int EQ, int NS, int DERIV, int NV>
+void rk4_trace_kernel_w2(const DevParams P_kernarg, const TraceArgs A_hot) {
+#define RAYS_RK4_USE_WINDOW 2
+#define RAYS_RK4_LONG_FIRST 0
+#include "rays_rk4_body.inc"
+#undef RAYS_RK4_LONG_FIRST
+#undef RAYS_RK4_USE_WINDOW
+}
 template <int EQ, int NS, int DERIV, int NV>
 void rk4_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
 #ifdef RAYS_RK4_DIRECT_STORES
@@ -64,7 +77,9 @@ void rk4_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
 #else
 #define RAYS_RK4_USE_WINDOW 1
 #endif
+#define RAYS_RK4_LONG_FIRST 1  // pass loop around the trip loop, rays handed out long-first (rays_rk4_body.inc)
 #include "rays_rk4_body.inc"
+#undef RAYS_RK4_LONG_FIRST
 #undef RAYS_RK4_USE_WINDOW
 }
 #endif

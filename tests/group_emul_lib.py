@@ -36,7 +36,7 @@ def _build(defs):
     srcs = [os.path.join(_DIR, f) for f in ("emul_group.cpp", "emul_trace.cpp", "hip/hip_runtime.h", "hip/hip_wave_emul.h")]
     srcs += [os.path.join(_ROOT, "rays_amd", "csrc", f) for f in
              ("rays_libm.hpp", "rays_device.hpp", "rays_trace.hpp", "rays_sg.hpp", "rays_sg_group.hpp", "rays_dev_params.inc",
-              "rays_rk4.hpp", "rays_rk4_body.inc")]
+              "rays_rk4.hpp", "rays_rk4_body.inc", "rays_rk4_pass.inc")]
     if os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs):
         return
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-extern-tls-init", "-fPIC",
@@ -105,9 +105,11 @@ def trace(p: RaysParams, rvec0, rindex_vec0, G: int = 8, resident_blocks: int = 
     return out
 
 
-def trace_rk4_waves(p: RaysParams, rvec0, rindex_vec0, nwaves: int = 1, library=None, stride: int = 0) -> dict:
+def trace_rk4_waves(p: RaysParams, rvec0, rindex_vec0, nwaves: int = 1, library=None, stride: int = 0,
+                    w2_body: bool = False) -> dict:
     """The one-ray-per-lane RK4 kernel on `nwaves` whole 64-lane waves (rays beyond 64 * nwaves are pulled by lanes
-    whose ray has ended; stride > 1: in the "long rays first" order of rays_trace.hpp: take_rays)."""
+    whose ray has ended; stride > 1: in the "long rays first" order of rays_trace.hpp: take_rays; w2_body: the
+    body of the two-waves-per-SIMD build -- one loop, index order, residual(:) alone through the LDS window)."""
     rvec0 = np.ascontiguousarray(rvec0, dtype=np.float64)
     rindex_vec0 = np.ascontiguousarray(rindex_vec0, dtype=np.float64)
     nray, nv, npt = len(rvec0), p.nv, p.nstep_max + 1
@@ -116,6 +118,7 @@ def trace_rk4_waves(p: RaysParams, rvec0, rindex_vec0, nwaves: int = 1, library=
                end_ray_vec=np.zeros((nray, nv)), end_residuals=np.zeros(nray), max_residuals=np.zeros(nray))
     d = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
     i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    (library or lib()).rays_emul_rk4_waves_use_w2_body(int(w2_body))
     rc = (library or lib()).rays_emul_trace_rk4_waves(C.byref(p), int(nwaves), int(stride), nray, d(rvec0), d(rindex_vec0),
                                                       d(out["ray_vec"]), d(out["residual"]), i(out["npoints"]),
                                                       i(out["stop_code"]), d(out["end_ray_vec"]), d(out["end_residuals"]),

@@ -69,16 +69,19 @@ extern "C" int rays_emul_trace_group(const rays_params_t* p, int G, int resident
 // The one-ray-per-lane kernels on whole waves: `nwaves` blocks of one 64-lane wave each.  Fewer lanes than rays: lanes
 // whose ray has ended are parked, written out and refilled by the wave's batched pass (rays_rk4_body.inc) -- the
 // control flow a single emulated lane cannot exercise (its ballots have one bit).
+static int g_rk4_w2_body = 0;  // run the body of the two-waves-per-SIMD build (one loop, index order, residual window)
 template <int EQ, int NS, int NV>
 static int run_rk4_waves(const rays::DevParams& D, const rays::TraceArgs& A, int nwaves) {
   gridDim.x = (unsigned)nwaves;
   blockDim.x = 64;
   for (int b = 0; b < nwaves; b++) {
     blockIdx.x = (unsigned)b;
-    wave_emul::run_wave(0u, [&] { rays::rk4_trace_kernel<EQ, NS, 0, NV>(D, A); }, threadIdx);
+    if (g_rk4_w2_body) wave_emul::run_wave(0u, [&] { rays::rk4_trace_kernel_w2<EQ, NS, 0, NV>(D, A); }, threadIdx);
+    else wave_emul::run_wave(0u, [&] { rays::rk4_trace_kernel<EQ, NS, 0, NV>(D, A); }, threadIdx);
   }
   return 0;
 }
+extern "C" void rays_emul_rk4_waves_use_w2_body(int on) { g_rk4_w2_body = on; }
 // stride > 1: the "long rays first" hand-out order (rays_trace.hpp: take_rays) with that neighbourhood size
 extern "C" int rays_emul_trace_rk4_waves(const rays_params_t* p, int nwaves, int stride, int nray, const double* rvec0,
                                          const double* rindex_vec0, double* ray_vec, double* residual, int32_t* npoints,

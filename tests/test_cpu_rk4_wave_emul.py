@@ -43,6 +43,8 @@ def test_solovev_fan_with_refills(variant, stride):
     ora = oracle_lib.trace(p, r0, n0)
     assert len(set(ora["npoints"].tolist())) > 20 and ora["npoints"][7] == 1
     _check(ge.trace_rk4_waves(p, r0, n0, nwaves=1, library=_lib(variant), stride=stride), ora)
+    if stride == 0:  # the two-waves-per-SIMD build's body (its own loop structure and hand-out)
+        _check(ge.trace_rk4_waves(p, r0, n0, nwaves=1, library=_lib(variant), w2_body=True), ora)
 
 
 @pytest.mark.parametrize("variant", ["default", "cost0"])
@@ -67,6 +69,7 @@ def test_slab_box_exits_two_waves(variant):
     assert len(set(ora["stop_code"].tolist())) > 1
     _check(ge.trace_rk4_waves(p, r0, n0, nwaves=2, library=_lib(variant)), ora)
     _check(ge.trace_rk4_waves(p, r0, n0, nwaves=2, library=_lib(variant), stride=4), ora)
+    _check(ge.trace_rk4_waves(p, r0, n0, nwaves=2, library=_lib(variant), w2_body=True), ora)
 
 
 def test_eqdsk_damping_fan_with_refills():
