@@ -58,8 +58,8 @@ struct TraceArgs {
 // traced first, as the PILOT of its neighbourhood (S - 1 rays close to it), and the others are handed out in two
 // sweeps over the neighbourhoods in index order: sweep 1 skips the neighbourhoods whose pilot has already ended (the
 // short ones) and hands out those whose pilot is still running (at that moment the longest rays there are); sweep 2
-// hands out what sweep 1 skipped.  tools/refill_model.py on cfg 5b's measured lengths: 773 trips in index order, 601-605
-// with this order, 589 with the rays sorted by their true lengths (ideal 518).  Every ray is handed out exactly
+// hands out what sweep 1 skipped.  tools/refill_model.py on cfg 5b's measured lengths: 773 trips in index order, 589 with
+// this order and S = 2 (605 with S = 4 or 8), 589 with the rays sorted by their true lengths (ideal 518).  Every ray is handed out exactly
 // once: a pilot by the counter, a neighbour by whoever sets its bit in the neighbourhood's state word first.  The
 // order changes no ray's arithmetic.
 //
