@@ -12,6 +12,8 @@ from bench import kernel_source_hash  # noqa: E402
 path = os.path.join(ROOT, "profiles", "counters.json")
 db = json.load(open(path)) if os.path.exists(path) else {}
 for f in sys.argv[1:]:
+    if "_index_order" in os.path.basename(f):  # comparison profiles (RAYS_HIP_RAY_ORDER=index): not what bench.py runs
+        continue
     s = json.load(open(f))
     c, d, b = s["counters"], s["derived"], s["bench_line"]
     m = lambda k: c[k]["mean_per_launch"] if k in c else None
