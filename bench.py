@@ -119,6 +119,48 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def numerics_evidence(cfg_name, flavour):
+    """What tests/test_gpu_numerics_full_fans.py MEASURED for this workload and flavour on the full fan (every recorded
+    step restarted from the oracle's point; every traced point against the oracle's), replayed from
+    profiles/numerics_evidence.json when it was collected from the kernel sources this run is built from."""
+    path = os.path.join(ROOT, "profiles", "numerics_evidence.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        e = json.load(open(path)).get(f"{cfg_name}::{flavour}")
+    except Exception as ex:
+        print(f"[bench] profiles/numerics_evidence.json unreadable: {ex}", file=sys.stderr)
+        return None
+    if not e:
+        return None
+    if e.get("source_hash") != kernel_source_hash():
+        print(f"[bench] profiles/numerics_evidence.json: {cfg_name}::{flavour} was measured on other kernel sources "
+              f"({e.get('source_hash')} != {kernel_source_hash()}): numerics_evidence omitted -- re-run "
+              "tests/test_gpu_numerics_full_fans.py on a GPU box and copy gpurun_out/numerics_evidence.json", file=sys.stderr)
+        return None
+    keys = ("steps_restarted", "n_above_1e-10", "n_above_1e-11", "max_per_step", "median_per_step", "points_compared",
+            "max_pointwise", "frac_points_above_1e-10", "rays_surveyed", "rays_with_other_counts", "kernel")
+    out = {k: e.get(k) for k in keys}
+    out["source"] = ("replayed from profiles/numerics_evidence.json (tests/test_gpu_numerics_full_fans.py on MI355X, kernel "
+                     "sources hash " + str(e.get("source_hash")) + "); not measured in this run")
+    return out
+
+
+def numerics_text(flavour, is_tol_kernel, ev):
+    if not (flavour == "tolerance" and is_tol_kernel):
+        return flavour + ": bit-identical to the reference CPU path" if flavour == "exact" else \
+            flavour + " requested; this configuration has no tolerance flavour: bit-identical to the reference CPU path"
+    base = ("tolerance: NOT bit-identical (FMA contraction, re-association, once-refined reciprocals and roots); ray counts / "
+            "step indices / stop flags exactly the reference's")
+    if ev is None:
+        return base + "; per-step and pointwise deviation of this build not measured (see value_exact for the bit-exact flavour)"
+    return (base + f" on all {ev['rays_surveyed']} rays surveyed; restarted from every one of the oracle's {ev['steps_restarted']} "
+            f"recorded points, {ev['n_above_1e-10']} steps land further than 1e-10 (relative, norm-wise on r and k) from the "
+            f"reference's next point, max {ev['max_per_step']:.2e}; accumulated along the rays the traced fan deviates "
+            f"pointwise by up to {ev['max_pointwise']:.1e} ({100.0 * ev['frac_points_above_1e-10']:.3f} % of points above 1e-10) "
+            "-- numerics_evidence; value_exact is the bit-identical flavour")
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -271,6 +313,23 @@ def cpu_baseline(cfg_path, budget_s=20.0):
                 sample=sample + f"; {steps} steps in {dt:.2f} s, C restatement (oracle/), OpenMP over rays")
 
 
+def host_entry_time(p, r0, n0, reps=3):
+    """What the reference's own call site sees (RAYS.f90:13 `call trace_rays` -> fortran/trace_rays_hip.f90 ->
+    rays_hip_trace): host arrays in and out, blocking, the caller's arrays resident (allocated and zero-filled once by
+    initialize_ray_results_m, as in the Fortran host).  PCIe-inclusive; never `value`."""
+    from rays_amd import hip
+
+    out = hip.trace_host(p, r0, n0, ngpu=1)        # first call: first touch of the caller's pages, buffer cache cold
+    steps = int(np.maximum(out["npoints"].astype(np.int64) - 1, 0).sum())
+    best, kern = None, None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = hip.trace_host(p, r0, n0, ngpu=1, out=out)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return dict(ms_per_call=1e3 * best, value=steps / best, kernel=hip.kernel_name(p, len(r0)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,6 +337,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "cfg3b_solovev64k_rk4.in"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-entry", action="store_true", help="skip the host_entry leg (rays_hip_trace on host arrays)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the trajectory gather (diagnostic)")
     ap.add_argument("--exchange", choices=("gather", "deposition"), default="gather",
                     help="what leaves the GPUs each pass: the packed trajectories, gathered to rank 0 "
@@ -460,6 +520,26 @@ def main():
                           "trace of pass i+1, so ms_per_step ~ max(trace, gather)); value_trace_only = the same K "
                           "passes with the exchange switched off; gather_ms = one exchange on its own")
 
+    # ---- N > 1: the same K passes when every rank's result STAYS on its GPU (a consumer with device-side
+    # post-processing) and only ray_results_m's per-ray summaries reach rank 0 (outside the timed region) ----
+    if world > 1 and args.exchange == "gather":
+        from rays_amd.exchange import SummaryGather
+
+        sg = SummaryGather(nray_total, nv, dev)
+        summ = lambda: sg.gather(tr.npoints, tr.stop_code, tr.end_ray_vec, tr.end_residuals, tr.max_residuals)
+        summ()
+        saved_gather, gather = gather, None
+        deposit_saved, deposit = deposit, summ
+        el_s, _ = timed(args.steps)
+        gather, deposit = saved_gather, deposit_saved
+        split.update(value_sharded_result=total_steps / (el_s / args.steps), sharded_result_ms_per_step=1e3 * el_s / args.steps,
+                     sharded_result_bytes_per_ray=sg.bytes_per_ray(),
+                     sharded_result_note="the same K passes; each rank's trajectories stay in its HBM, rank 0 receives npoints, "
+                                         "stop code, end_ray_vec, end_residuals, max_residuals of every ray (one grouped RCCL "
+                                         "send/recv per pass): the mode a device-side consumer of the trajectories runs "
+                                         "(deposition profiles, --exchange deposition); `value` above is trace + full gather as "
+                                         "the metric is defined and is bound by the root's ingest")
+
     # the timed passes must have reproduced the first pass (deterministic kernels)
     assert int(torch.clamp(tr.npoints.to(torch.int64) - 1, min=0).sum().item()) == steps_local
 
@@ -476,6 +556,8 @@ def main():
             tag = "exact" if args.numerics == "tolerance" else "tolerance"
             other = {f"value_{tag}": total_steps / (el_o / args.steps), f"ms_per_step_{tag}": 1e3 * el_o / args.steps,
                      f"kernel_{tag}": hip.kernel_name(p, hi - lo), "flavours_agree_on_npoints": same_counts}
+            if not same_counts:   # a tolerance kernel whose ray counts differ from the exact one's has no claim to the metric
+                raise SystemExit("bench.py: the tolerance and the exact flavour disagree on npoints for this fan -- no line")
         hip.set_numerics(args.numerics)
         tr.launch(zero_fill=False)     # leave the arrays as the timed flavour wrote them
         torch.cuda.synchronize()
@@ -528,6 +610,10 @@ def main():
             except Exception as e:
                 print(f"[bench] profiles/counters.json unreadable: {e}", file=sys.stderr)
         idle = simd_idle_fraction(tr.npoints.cpu().numpy()) if world == 1 else None
+        is_tol_kernel = "<" in kname and bool(int(kname.split("<")[1].split(",")[0]) & 16)
+        evidence = None
+        if args.fan_scale == 1 and args.nstep_max is None and world == 1:
+            evidence = numerics_evidence(os.path.basename(args.config), "tolerance" if is_tol_kernel else "exact")
         line = {
             "metric": metric_name(p, hi - lo),
             "value": value, "unit": "ray-steps/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps,
@@ -539,11 +625,7 @@ def main():
                        "ode": "RK4_ODE" if p.ode_solver == 0 else "SG_ODE",
                        "deriv": "cold" if p.ray_deriv == 0 else "numerical",
                        "kernel": hip.kernel_name(p, hi - lo),
-                       "numerics": (hip.get_numerics() + (": every step within 1e-10 relative of the reference's, ray counts / "
-                                    "step indices / stop flags exactly the reference's (tests/test_gpu_tolerance_flavour.py)"
-                                    if hip.get_numerics() == "tolerance" and "<" in hip.kernel_name(p, hi - lo) and
-                                    int(hip.kernel_name(p, hi - lo).split("<")[1].split(",")[0]) & 16
-                                    else ": bit-identical to the reference CPU path")),
+                       "numerics": numerics_text(hip.get_numerics(), is_tol_kernel, evidence),
                        "exchange": ("none" if world == 1 else
                                     ("skipped" if args.no_gather else "packed send/recv to rank 0 (RCCL)"))
                        if args.exchange == "gather" else
@@ -553,6 +635,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "counters": (None if traffic is None else
+                                      "traffic / roofline_fp64 counters replayed from profiles/counters.json (rocprofv3 --pmc passes of "
+                                      "this command on these kernel sources); achieved, kernel_ms and frac are measured in this run"),
                          "note": "the contract's HBM figure; the path is bound by FP64 instruction issue "
                                  "(roofline_fp64), not by HBM: DESIGN.md 4.5"},
         }
@@ -560,9 +645,26 @@ def main():
             line["roofline_fp64"] = fp64
         if idle is not None:
             line["simd_idle_frac"] = idle
+        if evidence is not None:
+            line["numerics_evidence"] = evidence
         line.update(split)
         if other is not None:
             line.update(other)
+        if world == 1 and not args.no_host_entry and args.exchange == "gather":
+            try:   # outside the timed region: the rate the reference's own call site sees, both flavours
+                del tr
+                torch.cuda.empty_cache()
+                he = host_entry_time(p, r0, n0)
+                other_flavour = "exact" if args.numerics == "tolerance" else "tolerance"
+                hip.set_numerics(other_flavour)
+                if hip.kernel_name(p, len(r0)) != he["kernel"]:
+                    he[other_flavour] = host_entry_time(p, r0, n0)
+                hip.set_numerics(args.numerics)
+                he["note"] = ("rays_hip_trace (the entry fortran/trace_rays_hip.f90 calls): pack on the GPU, packed D2H through "
+                              "pinned staging, host scatter into the caller's resident arrays; PCIe-inclusive, best of 3 calls")
+                line["host_entry"] = he
+            except Exception as e:
+                print(f"[bench] host_entry leg failed: {e}", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(line))

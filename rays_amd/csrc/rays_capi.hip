@@ -583,7 +583,15 @@ int rays_hip_check_params(const rays_params_t* p) {
   }
   if (p->ode_solver == RAYS_ODE_SG && (p->rel_err0 < (double)1.e-10f || p->abs_err0 < (double)1.e-10f))
     return fail("initialize_SG_ode: rel_err0, abs_err0 too small");  // SG_ode_m.f90:63-66
-  if (!find_kernel(*p)) return fail("rays_hip: no kernel specialisation for this configuration");
+  if (!find_kernel(*p)) {
+    char msg[256];
+    std::snprintf(msg, sizeof msg, "rays_hip: no kernel built for this configuration (%s, equilibrium %d, %d species, %s dD, "
+                  "nv = %d%s): the default library holds nspec = 1 plus the fixtures' shapes -- rebuild with "
+                  "`make -C rays_amd/csrc FULL=1` for every species count", p->ode_solver == RAYS_ODE_RK4 ? "RK4" : "SG",
+                  p->equilib_model, p->nspec + 1, p->ray_deriv == RAYS_DERIV_COLD ? "cold" : "numerical", p->nv,
+                  p->multi_spec_damping ? ", multi_spec_damping" : "");
+    return fail(msg);
+  }
   return 0;
 }
 

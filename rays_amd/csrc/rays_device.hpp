@@ -26,6 +26,14 @@ namespace rays {
 // rare per-ray events (a ray starts, stops, crashes): block-frequency hint for the register allocator,
 // which otherwise assumes 50 % and keeps their operands in reach on every trip
 #define RAYS_RARE(x) __builtin_expect(!!(x), 0)
+// First statement of a function body whose arithmetic decides an INDEX or a branch (spline cell searches): in the
+// tolerance-flavour translation units (-fassociative-math, FMA contraction) it is evaluated as written all the same.
+// Lexical: functions inlined into the body keep their own setting.  (Needs -ffp-contract=fast-honor-pragmas.)
+#if defined(__clang__) && defined(RAYS_TOL_FLAVOUR) && !defined(RAYS_HOST_EMUL)
+#define RAYS_FP_AS_WRITTEN _Pragma("clang fp reassociate(off) contract(off)")
+#else
+#define RAYS_FP_AS_WRITTEN
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Device parameter block: rays_params_t trimmed to what the kernels read, plus values the
@@ -532,6 +540,7 @@ typedef const __attribute__((address_space(3))) double* eq_lds_ptr;
 #endif
 template <class PTR>
 RAYS_DEV int spl_cell(PTR x, int nx, double xget, double& dx) {
+  RAYS_FP_AS_WRITTEN
   const double x1 = x[0], xn = x[nx - 1];
   double z = xget;
   if (z < x1) z = x1;
@@ -1203,10 +1212,12 @@ RAYS_DEV Cplx divdc3(Cplx x, Cplx y) {  // compiler-rt __divdc3, finite operands
 
 // x_grid(i), 1-based (zfunctions_m.f90:444); Rn = shared reciprocal of nx - 1 (six quotients per lookup)
 RAYS_DEV double zf_x(const DevParams& P, int i, const Recip& Rn) {
+  RAYS_FP_AS_WRITTEN
   return P.zf_xmin + div((double)(i - 1) * (P.zf_xmax - P.zf_xmin), Rn);
 }
 
 RAYS_DEV Cplx zfun_real_arg_spline(const DevParams& P, double z) {
+  RAYS_FP_AS_WRITTEN
   double re;
   if (fabs(z) <= 10.0) {  // spline_range
     const int nxm = P.zf_nx - 1;

@@ -4,9 +4,12 @@
 //   -DRAYS_INST_EQT=<EQ + 4 UE + 8 MS + 16 TOL>  (the kernels' EQ template argument as a literal, for the kernel names)
 //   -DRAYS_INST_TOL=1 -DRAYS_TOL_FLAVOUR -ffp-contract=fast: the tolerance flavour of a cold RK4 group
 //   (rays_device.hpp: kEqTol; 1e-10 relative per step instead of bit-identity)
-// Each group instantiates the species counts NS = 1..6 (nspec = 0..5, species_m.f90:25) and
-// nv = 7 | 12 (integrate_eq_gradients) and 8 | 13 (+ damping) (ode_m.f90:160-173); the MS = 1 groups
-// (multi_spec_damping) nv = 8 + NS | 13 + NS.
+// `make FULL=1` (-DRAYS_INST_FULL): each group instantiates the species counts NS = 1..6 (nspec = 0..5,
+// species_m.f90:25) and nv = 7 | 12 (integrate_eq_gradients) and 8 | 13 (+ damping) (ode_m.f90:160-173); the MS = 1
+// groups (multi_spec_damping) nv = 8 + NS | 13 + NS.  The DEFAULT build holds electrons + one ion species (NS = 2) in
+// every nv, plus the other species counts a BASELINE config or a fixture reaches (listed below): a quarter of the
+// kernels, of the build time and of the library's size.  A configuration whose shape is not built is refused with a
+// message that names `make FULL=1` (rays_capi.hip: find_kernel).
 #include "rays_launch.hpp"
 #if RAYS_INST_SOLVER == 0
 #include "rays_rk4.hpp"
@@ -110,7 +113,7 @@ hipError_t launch_group(const DevParams& P, const TraceArgs& A, hipStream_t stre
 const KernelEntry kEntries[] = {
 #if RAYS_INST_MS
     // multi_spec_damping: nv = 7 + 1 + (1 + nspec) (+ 5 with integrate_eq_gradients), ode_m.f90:160-173
-#ifdef RAYS_INST_FAST
+#if defined(RAYS_INST_FAST) || !defined(RAYS_INST_FULL)
     RAYS_ENTRY(2, 10), RAYS_ENTRY(2, 15),
 #else
     RAYS_ENTRY(1, 9), RAYS_ENTRY(2, 10), RAYS_ENTRY(3, 11), RAYS_ENTRY(4, 12), RAYS_ENTRY(5, 13), RAYS_ENTRY(6, 14),
@@ -123,6 +126,26 @@ const KernelEntry kEntries[] = {
 #endif
 #if RAYS_INST_SOLVER == 0 && RAYS_INST_EQ != 2 && !defined(RAYS_HOST_EMUL)
     RAYS_ENTRY_OCC2(2, 7),
+#endif
+#elif !defined(RAYS_INST_FULL)  // the default build: NS = 2 throughout + the shapes configs / fixtures reach
+    RAYS_ENTRY(2, 7), RAYS_ENTRY(2, 12), RAYS_ENTRY(2, 8), RAYS_ENTRY(2, 13),
+#ifdef RAYS_INST_GROUP
+    RAYS_ENTRY_GROUP(2),
+#endif
+#if RAYS_INST_SOLVER == 0 && RAYS_INST_EQ != 2
+    RAYS_ENTRY_OCC2(2, 7),
+#endif
+#if RAYS_INST_SOLVER == 0 && RAYS_INST_EQ == 0 && RAYS_INST_DERIV == 0 && RAYS_INST_UE == 1
+    RAYS_ENTRY(1, 7), RAYS_ENTRY_OCC2(1, 7),   // electrons only (gold_slab_ns1_rk4)
+#endif
+#if RAYS_INST_SOLVER == 1 && RAYS_INST_EQ == 0 && RAYS_INST_DERIV == 1 && RAYS_INST_UE == 1
+    RAYS_ENTRY(3, 7), RAYS_ENTRY_GROUP(3),     // three species (gold_slab_shear_gauss_3spec_sg_num)
+#endif
+#if RAYS_INST_SOLVER == 0 && RAYS_INST_EQ == 1 && RAYS_INST_DERIV == 1 && RAYS_INST_UE == 1
+    RAYS_ENTRY(4, 7),                          // D + T + 3He (gold_solovev64_4spec_rk4_num)
+#endif
+#if RAYS_INST_SOLVER == 1 && RAYS_INST_EQ == 0 && RAYS_INST_DERIV == 0 && RAYS_INST_UE == 1
+    RAYS_ENTRY(6, 7),                          // five ion species (gold_slab_6spec_sg)
 #endif
 #else
     RAYS_ENTRY(1, 7), RAYS_ENTRY(2, 7), RAYS_ENTRY(3, 7), RAYS_ENTRY(4, 7), RAYS_ENTRY(5, 7), RAYS_ENTRY(6, 7),

@@ -38,6 +38,15 @@
 namespace rays {
 namespace libm {
 
+// The tolerance-flavour translation units are compiled with -fassociative-math and FMA contraction (Makefile:
+// TOLFLAGS).  Neither may touch this file: the compensated terms below (lo2 = t1 - t2 + r, lo4 = t2 - hi0 + ar2,
+// loglo = hi0 - loghi + lo, ...) are exact-arithmetic identities that re-association folds to 0, and every FMA of
+// glibc's build is written out.  The pragmas need -ffp-contract=fast-honor-pragmas (plain `fast` fuses in the backend
+// whatever the source says); tests/test_cpu_libm.py builds this header with TOLFLAGS and compares it with libm.
+#if defined(__clang__) && defined(RAYS_TOL_FLAVOUR)
+#pragma clang fp reassociate(off) contract(off)
+#endif
+
 #include "rays_libm_tables.inc"
 
 typedef unsigned long long u64;
@@ -227,6 +236,10 @@ RAYS_LIBM_FN double pow(double x, double y) {
   const double scale = asf64(sbits);
   return fma_(etmp, scale, scale);
 }
+
+#if defined(__clang__) && defined(RAYS_TOL_FLAVOUR)
+#pragma clang fp reassociate(on) contract(fast)  // back to the translation unit's TOLFLAGS
+#endif
 
 }  // namespace libm
 }  // namespace rays

@@ -191,6 +191,55 @@ class TrajectoryGather:
         self.finish()
 
 
+class SummaryGather:
+    """The exchange of a run whose trajectories STAY on the GPU that traced them (a consumer with device-side
+    post-processing): rank 0 receives only the per-ray summaries of ray_results_m -- npoints, the stop
+    code, end_ray_vec(nv), end_residuals, max_residuals: 8 (nv + 2) + 8 bytes per ray (~ 80-100 B) instead of the ray's
+    packed trajectory (64 B per recorded step).  One grouped batch of receives on rank 0, one send per peer; the rows
+    travel as one float64 block per rank (npoints and stop codes are exact in a double)."""
+
+    def __init__(self, nray_total: int, nv: int, device, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.group = torch, dist, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.nv, self.device = nv, device
+        self.bounds = [shard_bounds(nray_total, self.world, r) for r in range(self.world)]
+        self.nrays = [hi - lo for lo, hi in self.bounds]
+        self.width = nv + 4
+        f64 = torch.float64
+        self._send = torch.zeros((self.nrays[self.rank], self.width), dtype=f64, device=device)
+        if self.rank == 0:
+            self.table = torch.zeros((nray_total, self.width), dtype=f64, device=device)
+
+    def bytes_per_ray(self) -> int:
+        return 8 * self.width
+
+    def gather(self, npoints, stop_code, end_ray_vec, end_residuals, max_residuals):
+        """Returns rank 0's [nray_total][nv + 4] table (columns: npoints, stop code, end_ray_vec, end_residuals,
+        max_residuals), None elsewhere."""
+        t, dist = self.torch, self.dist
+        s = self._send
+        s[:, 0].copy_(npoints)
+        s[:, 1].copy_(stop_code)
+        s[:, 2:2 + self.nv].copy_(end_ray_vec)
+        s[:, 2 + self.nv].copy_(end_residuals)
+        s[:, 3 + self.nv].copy_(max_residuals)
+        if self.rank == 0:
+            lo, hi = self.bounds[0]
+            self.table[lo:hi].copy_(s)
+            ops = [dist.P2POp(dist.irecv, self.table[self.bounds[r][0]:self.bounds[r][1]], r, self.group)
+                   for r in range(1, self.world) if self.nrays[r] > 0]
+            for w in (dist.batch_isend_irecv(ops) if ops else []):
+                w.wait()
+            return self.table
+        if self.nrays[self.rank] > 0:
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, s, 0, self.group)]):
+                w.wait()
+        return None
+
+
 class ProfileChain:
     """Ray-ordered reduction of deposition profiles across ranks holding consecutive ray blocks.
 

@@ -194,9 +194,12 @@ def check_params(p: RaysParams):
 
 def kernel_name(p: RaysParams, nray: int = 0) -> str:
     """Kernel specialisation a trace of `nray` rays would launch (0: the default build)."""
-    if nray:
-        return load().rays_hip_kernel_name_for(C.byref(p), int(nray)).decode()
-    return load().rays_hip_kernel_name(C.byref(p)).decode()
+    lib = load()
+    name = (lib.rays_hip_kernel_name_for(C.byref(p), int(nray)) if nray else lib.rays_hip_kernel_name(C.byref(p))).decode()
+    if not name:   # refused parameters or a shape the library was not built with (make FULL=1): never a silent ""
+        check_params(p)
+        raise RaysHipError("rays_hip_kernel_name: no kernel for this configuration")
+    return name
 
 
 def _dp(a):

@@ -130,3 +130,55 @@ def test_two_rank_gather_gloo():
         pr.join(timeout=300)
         assert pr.exitcode == 0
     assert q.get(timeout=10) is True
+
+
+def _summary_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rays_amd.exchange import SummaryGather, shard_bounds
+        from tests import oracle_lib
+
+        g, nml, p = load_golden("cfg2_solovev1024_rk4")
+        r0, n0 = g["rvec0"][:9], g["rindex_vec0"][:9]  # uneven blocks 5 + 4
+        lo, hi = shard_bounds(len(r0), world, rank)
+        out = oracle_lib.trace(p, r0[lo:hi], n0[lo:hi], nthreads=1)
+        sg = SummaryGather(len(r0), p.nv, torch.device("cpu"))
+        tab = None
+        for _ in range(2):
+            tab = sg.gather(*(torch.from_numpy(out[k]) for k in ("npoints", "stop_code", "end_ray_vec", "end_residuals",
+                                                                 "max_residuals")))
+        if rank == 0:
+            full = oracle_lib.trace(p, r0, n0, nthreads=1)
+            t = tab.numpy()
+            ok = (np.array_equal(t[:, 0], full["npoints"]) and np.array_equal(t[:, 1], full["stop_code"])
+                  and np.array_equal(t[:, 2:2 + p.nv], full["end_ray_vec"], equal_nan=True)
+                  and np.array_equal(t[:, 2 + p.nv], full["end_residuals"])
+                  and np.array_equal(t[:, 3 + p.nv], full["max_residuals"]) and sg.bytes_per_ray() == 8 * (p.nv + 4))
+            if not ok:
+                print("summary gather mismatch:", [bool(np.array_equal(t[:, 0], full["npoints"])), bool(np.array_equal(t[:, 1], full["stop_code"])),
+                      bool(np.array_equal(t[:, 2:2 + p.nv], full["end_ray_vec"])), bool(np.array_equal(t[:, 2 + p.nv], full["end_residuals"])),
+                      bool(np.array_equal(t[:, 3 + p.nv], full["max_residuals"]))], flush=True)
+            q.put(bool(ok))
+        else:
+            assert tab is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_summary_gather_gloo():
+    """The exchange of a run whose trajectories stay on their GPUs: only ray_results_m's per-ray summaries reach rank 0."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_summary_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(timeout=300)
+        assert pr.exitcode == 0
+    assert q.get(timeout=10) is True

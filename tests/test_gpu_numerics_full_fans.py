@@ -1,0 +1,88 @@
+"""GPU tier: what the numerics of the kernels bench.py runs ARE on the BASELINE fans at full size, measured against the
+oracle (tests/numerics_survey.py) -- not on 30 rays of a fixture:
+
+  * cfg 3b, the headline fan: all 65 536 rays, every one of its 12.87 M recorded steps restarted from the oracle's point;
+  * cfg 5b (eqdsk + damping): all 262 144 rays;
+  * cfg 4 (slab, 1 M rays, two-waves build): every 16th ray.
+
+For the tolerance flavour the test records and bounds: steps above 1e-10 / 1e-11 (north_star's per-step bar), the
+largest per-step error, the largest POINTWISE deviation of the traced fan from the oracle and the share of points
+above 1e-10; ray counts and stop codes of every surveyed ray must be the oracle's.  For the exact flavour everything must
+be zero.  The numbers go to gpurun_out/numerics_evidence.json (copied to profiles/numerics_evidence.json, which
+bench.py quotes in its line as `numerics_evidence`, labelled as replayed and keyed by the kernel sources' hash)."""
+import json
+import os
+
+import pytest
+
+import bench
+from rays_amd import hip
+from tests import oracle_lib
+from tests.common import ROOT
+from tests.numerics_survey import survey
+
+pytestmark = pytest.mark.gpu
+
+# config, ray stride, states per restart call (below / from 131072: the one-wave / two-waves build, as the fan dispatches)
+FANS = [("cfg3b_solovev64k_rk4.in", 1, 65536), ("cfg5b_axisym256k_rk4_damp.in", 1, 65536), ("cfg4_slab1M_rk4.in", 16, 262144)]
+
+# Bounds of the tolerance flavour, per config: (steps above 1e-10, max per step, max pointwise).  Measured values are in
+# profiles/numerics_evidence.json; the bounds leave a factor ~2 for another compiler's instruction selection.
+BOUNDS = {
+    "cfg3b_solovev64k_rk4.in": dict(n_above=40, max_per_step=2e-9, max_pointwise=5e-8),
+    "cfg5b_axisym256k_rk4_damp.in": dict(n_above=0, max_per_step=1e-10, max_pointwise=1e-9),
+    "cfg4_slab1M_rk4.in": dict(n_above=0, max_per_step=1e-10, max_pointwise=1e-6),
+}
+
+
+def _record(cfg, flavour, res):
+    d = os.path.join(ROOT, "gpurun_out")
+    if not os.path.isdir(d):
+        return
+    path = os.path.join(d, "numerics_evidence.json")
+    db = json.load(open(path)) if os.path.exists(path) else {}
+    res = dict(res, source_hash=bench.kernel_source_hash())
+    db[f"{cfg}::{flavour}"] = res
+    json.dump(db, open(path, "w"), indent=1, sort_keys=True)
+
+
+def _fan(cfg):
+    nml, p, r0, n0 = bench.build_fan(os.path.join(ROOT, "configs", cfg), 1, 1, None)
+    if bench.build_fan.tables is not None:
+        oracle_lib.set_axisym_tables(bench.build_fan.tables)
+    return p, r0, n0
+
+
+@pytest.mark.parametrize("cfg,stride,batch", FANS)
+def test_tolerance_flavour_on_the_full_fan(cfg, stride, batch):
+    prev = hip.set_numerics("tolerance")
+    try:
+        p, r0, n0 = _fan(cfg)
+        eq = int(hip.kernel_name(p, len(r0)).split("<")[1].split(",")[0])
+        assert eq & 16, hip.kernel_name(p, len(r0))
+        assert hip.kernel_name(p, batch) == hip.kernel_name(p, len(r0)), "restarts must run the build the fan dispatches"
+        res = survey(p, r0, n0, ray_stride=stride, restart_batch=batch, progress=print)
+    finally:
+        hip.set_numerics(prev)
+    _record(cfg, "tolerance", res)
+    print(json.dumps(res))
+    b = BOUNDS[cfg]
+    assert res["rays_with_other_counts"] == 0, "a ray count / stop code differs from the oracle's"
+    assert res["restarts_stopped"] == 0
+    assert res["n_above_1e-10"] <= b["n_above"], res["worst_steps"]
+    assert res["max_per_step"] <= b["max_per_step"], res["worst_steps"]
+    assert res["max_pointwise"] <= b["max_pointwise"]
+
+
+@pytest.mark.parametrize("cfg,stride,batch", [FANS[0]])
+def test_exact_flavour_on_the_full_headline_fan(cfg, stride, batch):
+    """The exact kernel on the same survey: every restarted step and every traced point IS the oracle's."""
+    prev = hip.set_numerics("exact")
+    try:
+        p, r0, n0 = _fan(cfg)
+        res = survey(p, r0, n0, ray_stride=stride, restart_batch=batch, progress=print)
+    finally:
+        hip.set_numerics(prev)
+    _record(cfg, "exact", res)
+    assert res["rays_with_other_counts"] == 0 and res["restarts_stopped"] == 0
+    assert res["max_per_step"] == 0.0 and res["max_pointwise"] == 0.0

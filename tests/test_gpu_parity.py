@@ -29,6 +29,16 @@ SG_CASES = ["gold_solovev64_sg_cold", "gold_solovev64_sg_num", "gold_solovev64_d
             "gold_slab_shear_gauss_3spec_sg_num", "gold_slab_6spec_sg", "gold_solovev64_damp_multi_sg",
             "gold_axisym64_solmag_sg_num", "gold_axisym64_eqlin_tspline_sg_num"]
 
+def test_bit_exact_bar_is_the_bar_applied():
+    """A green GPU run must mean the bit-exact bars were applied.  The kernels carry their own exp / pow, so their
+    comparisons with the fixtures are exact on any host; the ORACLE (tests vs the oracle, smoke) calls the host's libm and
+    is the reference's equal only where that is glibc's x86-64 FMA build -- asserted here, measured, not assumed."""
+    from tests.common import host_libm_check_ran, host_libm_is_the_variant_the_fixtures_were_cut_with
+    assert host_libm_check_ran(), "the host-libm comparison could not be built on this box"
+    assert host_libm_is_the_variant_the_fixtures_were_cut_with(), \
+        "this host's libm is not the variant the fixtures were cut with: oracle comparisons are not bit-exact here"
+
+
 @pytest.mark.parametrize("name", RK4_CASES)
 def test_rk4_matches_reference_golden(name):
     g, nml, p = load_golden(name)
