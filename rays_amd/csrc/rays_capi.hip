@@ -128,7 +128,7 @@ std::atomic<int> g_numerics{initial_numerics()};
 
 // nray: fan size (0 = unknown).  From two waves per SIMD worth of rays on, the two-waves-per-SIMD build
 // of the kernel is preferred where one exists (rays_rk4.hpp).
-const rays::KernelEntry* find_kernel(const rays_params_t& p, long long nray = 0) {
+const rays::KernelEntry* find_kernel(const rays_params_t& p, long long nray = 0, bool force_exact = false) {
   using namespace rays;
   typedef const KernelEntry* (*Getter)(int*);
   // [solver][equilibrium][derivative][unit exponents][multi_spec_damping]
@@ -143,7 +143,7 @@ const rays::KernelEntry* find_kernel(const rays_params_t& p, long long nray = 0)
                                            {rays_entries_tol_0_1_0_0_0, rays_entries_tol_0_1_0_1_0},
                                            {rays_entries_tol_0_2_0_0_0, rays_entries_tol_0_2_0_1_0}};
   int n = 0;
-  const bool tol = g_numerics.load() == RAYS_NUMERICS_TOLERANCE && p.ode_solver == RAYS_ODE_RK4 &&
+  const bool tol = !force_exact && g_numerics.load() == RAYS_NUMERICS_TOLERANCE && p.ode_solver == RAYS_ODE_RK4 &&
                    p.ray_deriv == RAYS_DERIV_COLD && !p.multi_spec_damping;
   const KernelEntry* e = tol ? tol_getters[p.equilib_model][unit_exponents(p) ? 1 : 0](&n)
                              : getters[p.ode_solver][p.equilib_model][p.ray_deriv][unit_exponents(p) ? 1 : 0]
@@ -700,9 +700,28 @@ int launch_trace(const rays_params_t* p, int nray, const double* d_rvec0, const 
       if (p->axisym.t_prof_model[is] == RAYS_AXI_T_SPLINE && (g_axi.n_te < 2 || g_axi.n_ti < 2)) need_t = true;
     if (need_ne || need_t) return fail("axisym_toroid: spline profile model selected but its table was not set");
   }
+  // A tolerance-flavour kernel hands its ill-conditioned steps over to the reference's arithmetic (rays_rk4_body.inc:
+  // kStopResumeExact): the exact twin's resume kernel follows it on the stream.  The hand-over travels in the per-ray
+  // summaries, so they exist for such a launch whether or not the caller asked for them.
+  const rays::KernelEntry* twin = nullptr;
+  if (kernel->eq & rays::kEqTol) {
+    twin = find_kernel(*p, 0, true);
+    if (!twin || !twin->resume) return fail("rays_hip: the tolerance kernel's exact twin is not in this build");
+    if (!A.end_ray_vec || !A.max_residuals) {
+      double* ws = nullptr;
+      rc = get_sg_workspace(stream, sizeof(double) * ((size_t)p->nv + 1) * (size_t)nray, &ws);  // (no SG kernel runs with it at the same time: one stream)
+      if (rc) return rc;
+      if (!A.end_ray_vec) A.end_ray_vec = ws;
+      if (!A.max_residuals) A.max_residuals = ws + (size_t)p->nv * (size_t)nray;
+    }
+  }
   int grid = 0;
   hipError_t e = kernel->launch(D, A, stream, &grid);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  if (twin) {
+    e = twin->resume(D, A, stream);
+    if (e != hipSuccess) return hip_fail(e, "resume kernel launch");
+  }
   return counter_launched(counter_slot, stream);
 }
 }  // namespace

@@ -80,6 +80,18 @@ hipError_t launch_one(const DevParams& P, const TraceArgs& A, hipStream_t stream
 #endif
 }
 
+#if RAYS_INST_SOLVER == 0 && RAYS_INST_DERIV == 0 && !RAYS_INST_TOL && !RAYS_INST_MS
+// the continuation of rays the tolerance twin of this shape hands over (rays_rk4.hpp: rk4_resume_kernel)
+template <int NS, int NV>
+hipError_t resume_one(const DevParams& P, const TraceArgs& A, hipStream_t stream) {
+  hipLaunchKernelGGL((rk4_resume_kernel<EQ, NS, DERIV, NV>), dim3((A.nray + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, P, A);
+  return hipGetLastError();
+}
+#define RAYS_RESUME(NS, NV) , &resume_one<NS, NV>
+#else
+#define RAYS_RESUME(NS, NV)
+#endif
+
 #ifdef RAYS_INST_GROUP
 #ifndef RAYS_SG_GROUP_LANES
 #define RAYS_SG_GROUP_LANES 4
@@ -105,7 +117,7 @@ hipError_t launch_group(const DevParams& P, const TraceArgs& A, hipStream_t stre
 #define RAYS_SG_FAR(NV) sg_far_doubles_per_lane<NV>()
 #endif
 #define RAYS_ENTRY(NS, NV) \
-  { RAYS_INST_SOLVER, EQ, NS, DERIV, NV, 1, RAYS_SG_FAR(NV), 1, RAYS_KNAME "<" RAYS_STR(RAYS_INST_EQT) ", " #NS ", " RAYS_STR(RAYS_INST_DERIV) ", " #NV ">", &launch_one<NS, NV> }
+  { RAYS_INST_SOLVER, EQ, NS, DERIV, NV, 1, RAYS_SG_FAR(NV), 1, RAYS_KNAME "<" RAYS_STR(RAYS_INST_EQT) ", " #NS ", " RAYS_STR(RAYS_INST_DERIV) ", " #NV ">", &launch_one<NS, NV> RAYS_RESUME(NS, NV) }
 // two-waves-per-SIMD build of an RK4 kernel (large fans; rays_rk4.hpp)
 #define RAYS_ENTRY_OCC2(NS, NV) \
   { RAYS_INST_SOLVER, EQ, NS, DERIV, NV, 2, 0, 1, "rk4_trace_kernel_w2<" RAYS_STR(RAYS_INST_EQT) ", " #NS ", " RAYS_STR(RAYS_INST_DERIV) ", " #NV ">", &launch_one<NS, NV, 2> }

@@ -27,6 +27,9 @@ struct KernelEntry {
   const char* name;
   // Launches on `stream` with a grid sized for full residency (persistent waves + lane refill).
   hipError_t (*launch)(const DevParams&, const TraceArgs&, hipStream_t stream, int* grid_blocks);
+  // exact cold RK4 shapes: rk4_resume_kernel, the continuation of the rays their TOLERANCE twin hands over
+  // (rays_rk4_body.inc: kStopResumeExact); null elsewhere
+  hipError_t (*resume)(const DevParams&, const TraceArgs&, hipStream_t stream);
 };
 
 constexpr int kBlock = 256;

@@ -26,6 +26,84 @@
 
 namespace rays {
 
+// ---- rk4_resume_ray: a ray the tolerance kernels handed over, continued to its end as trace_rays has it ----------
+// (ray_tracing.f90:118-260, RK4_ode_m.f90:59-94), one ray per lane, plainly: step, check_save, record, next.  The
+// tolerance kernel left the ray with stop code kStopResumeExact, npoints so far, v at the start of the step it did not
+// commit (end_ray_vec), the running maximum of the residuals (max_residuals); the recorded residuals are in the array.
+// Only instantiated in EXACT translation units (rays_inst.hip), so its arithmetic is the reference's and the points it
+// records are the exact kernels', bit for bit -- tests/test_gpu_tolerance_flavour.py hands WHOLE rays over to check that.
+// A handful of steps per ray at most (the last one or two of a ray that runs into dD/dw -> 0): divergence and the five
+// evaluations per step (four stages + check_save, not fused here) do not matter; points are stored directly.
+template <int EQ, int NS, int DERIV, int NV>
+RAYS_DEV void rk4_resume_ray(const DevParams& P, const TraceArgs& A, int ray) {
+  const long long npt = (long long)P.nstep_max + 1;
+  double v[NV], w[NV];
+#pragma unroll
+  for (int i = 0; i < NV; i++) v[i] = A.end_ray_vec[(long long)ray * NV + i];
+  int nstep = A.npoints[ray] - 1;
+  double maxr = A.max_residuals[ray];
+  double last_resid = A.residual[(long long)ray * npt + nstep];
+  double prev_resid = nstep >= 1 ? A.residual[(long long)ray * npt + nstep - 1] : 0.;
+  double ds_ray = P.ds;
+  if (A.rays_per_run > 0) ds_ray = A.ds_run[ray / A.rays_per_run];
+  // the ray parameter as trace_rays accumulates it: sout = sout + ds, once per step taken (start_ray, rays_rk4_body.inc)
+  double sout = A.s0 ? A.s0[ray] : 0., s = sout;
+  for (int k = 0; k <= nstep; k++) {
+    s = sout;
+    sout = sout + ds_ray;
+  }
+  int stop;
+  for (;;) {
+    const double dsl = sout - s;  // RK4_ode_m.f90:81
+    stop = rk4_step_as_reference<EQ, NS, DERIV, NV>(P, v, dsl, w);
+    if (stop) break;  // :83-89 a stage refused: v untouched, the ray ends
+    double f[NV], resid;
+    int code, cs_flag;
+    bool cs_stop;
+    rhs_eval<EQ, NS, DERIV, NV>(P, w, true, resid, cs_flag, cs_stop, code, f);  // check_save + the next step's first stage
+#pragma unroll
+    for (int i = 0; i < NV; i++) v[i] = w[i];
+    s = sout;
+    if (cs_stop) {  // ray_tracing.f90:214-234: step not recorded, v is the new state
+      stop = cs_flag;
+      break;
+    }
+    nstep = nstep + 1;  // :237-243
+    record_point<NV>(A, (long long)ray * npt + nstep, v, resid);
+    if (fabs(last_resid) > maxr) maxr = fabs(last_resid);
+    prev_resid = last_resid;
+    last_resid = resid;
+    sout = sout + ds_ray;  // :118-172
+    if (sout > P.s_max) {
+      stop = RAYS_STOP_SOUT_GT_SMAX;
+      break;
+    }
+    if (nstep + 1 > P.nstep_max) {
+      stop = RAYS_STOP_NSTEP_MAX;
+      break;
+    }
+    if (code) {  // first RK4 stage of the next step stops (RK4_ode_m.f90:82-83)
+      stop = code;
+      break;
+    }
+  }
+  A.npoints[ray] = nstep + 1;  // ray_tracing.f90:252-260
+  A.stop_code[ray] = stop;
+#pragma unroll
+  for (int i = 0; i < NV; i++) A.end_ray_vec[(long long)ray * NV + i] = v[i];
+  if (A.end_residuals) A.end_residuals[ray] = nstep >= 1 ? prev_resid : 0.;
+  A.max_residuals[ray] = maxr;
+}
+
+// one lane per ray of the launch; lanes whose ray was not handed over leave at once
+template <int EQ, int NS, int DERIV, int NV>
+__global__ void __launch_bounds__(256)
+rk4_resume_kernel(const DevParams P, const TraceArgs A) {
+  const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= A.nray || A.stop_code[ray] != kStopResumeExact) return;
+  rk4_resume_ray<EQ, NS, DERIV, NV>(P, A, ray);
+}
+
 #ifndef RAYS_HOST_EMUL
 // One wave per SIMD (all 256 VGPRs): fastest while the fan has at most one wave per SIMD (<= 64k rays).
 template <int EQ, int NS, int DERIV, int NV>

@@ -20,6 +20,10 @@
 namespace rays {
 
 constexpr int kWave = 64;
+// Internal stop code of the tolerance-flavour RK4 kernels: "this ray's next step is ill-conditioned; rk4_resume_kernel
+// continues it in the reference's arithmetic" (rays_rk4_body.inc).  Never leaves the library: every launch of such a
+// kernel is followed by the resume kernel, which overwrites it with the ray's real stop code.
+constexpr int kStopResumeExact = 1000;
 
 struct TraceArgs {
   int nray;

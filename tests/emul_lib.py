@@ -36,7 +36,7 @@ def build(sanitize: bool = False, out: str = None, defs=()):
 def _build(sanitize, defs):
     srcs = [os.path.join(_DIR, "emul_trace.cpp"), os.path.join(_DIR, "hip", "hip_runtime.h")]
     srcs += [os.path.join(_ROOT, "rays_amd", "csrc", f) for f in
-             ("rays_libm.hpp", "rays_libm_tables.inc", "rays_device.hpp", "rays_trace.hpp", "rays_rk4.hpp", "rays_rk4_body.inc", "rays_rk4_pass.inc", "rays_sg.hpp", "rays_dev_params.inc",
+             ("rays_libm.hpp", "rays_libm_tables.inc", "rays_device.hpp", "rays_device_arith.inc", "rays_trace.hpp", "rays_rk4.hpp", "rays_rk4_body.inc", "rays_rk4_pass.inc", "rays_sg.hpp", "rays_dev_params.inc",
               "rays_ray_init.hpp", "rays_fan_setup.inc", "rays_deposition.hpp")]
     if os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs):
         return

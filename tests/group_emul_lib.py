@@ -35,7 +35,7 @@ def build(out=None, defs=()):
 def _build(defs):
     srcs = [os.path.join(_DIR, f) for f in ("emul_group.cpp", "emul_trace.cpp", "hip/hip_runtime.h", "hip/hip_wave_emul.h")]
     srcs += [os.path.join(_ROOT, "rays_amd", "csrc", f) for f in
-             ("rays_libm.hpp", "rays_device.hpp", "rays_trace.hpp", "rays_sg.hpp", "rays_sg_group.hpp", "rays_dev_params.inc",
+             ("rays_libm.hpp", "rays_device.hpp", "rays_device_arith.inc", "rays_trace.hpp", "rays_sg.hpp", "rays_sg_group.hpp", "rays_dev_params.inc",
               "rays_rk4.hpp", "rays_rk4_body.inc", "rays_rk4_pass.inc")]
     if os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs):
         return

@@ -1,5 +1,6 @@
 // TEST INFRASTRUCTURE ONLY: runs the product trace kernels lane-by-lane on the CPU (see
 // hip/hip_runtime.h in this directory).  Exposes one C entry used by tests/test_cpu_kernel_emul.py.
+#define RAYS_EMUL_HANDOVER 1   // the tolerance kernels' hand-over of ill-conditioned steps + rk4_resume_ray, on the host
 #include <hip/hip_runtime.h>
 #include <vector>
 RAYS_EMUL_DEFINE_GLOBALS
@@ -17,8 +18,16 @@ RAYS_EMUL_DEFINE_GLOBALS
 template <int EQ, int DERIV, int NS, int NV>
 static int run1(int solver, const rays::DevParams& D, const rays::TraceArgs& A) {
   threadIdx.x = 0; blockIdx.x = 0; blockDim.x = 1; gridDim.x = 1;
-  if (solver == 0) rays::rk4_trace_kernel<EQ, NS, DERIV, NV>(D, A);
-  else rays::sg_trace_kernel<EQ, NS, DERIV, NV>(D, A);
+  if (solver == 0) {
+    rays::rk4_trace_kernel<EQ, NS, DERIV, NV>(D, A);
+    for (int ray = 0; ray < A.nray; ray++)   // what rays_capi.hip launches behind a tolerance kernel: rk4_resume_kernel
+      if (A.stop_code[ray] == rays::kStopResumeExact) {
+        rays::rays_emul_redo_steps++;
+        rays::rk4_resume_ray<EQ, NS, DERIV, NV>(D, A, ray);
+      }
+  } else {
+    rays::sg_trace_kernel<EQ, NS, DERIV, NV>(D, A);
+  }
   return 0;
 }
 template <int EQ, int DERIV>
@@ -47,6 +56,12 @@ static int run_ms(int solver, int ns, int nv, const rays::DevParams& D, const ra
     if (ns == 2 && nv == 15) return run1<EQ, DERIV, 2, 15>(solver, D, A);
   }
   return 1;
+}
+
+extern "C" long long rays_emul_redo_steps(int reset) {
+  const long long n = rays::rays_emul_redo_steps.load();
+  if (reset) rays::rays_emul_redo_steps = 0;
+  return n;
 }
 
 static std::vector<double> g_zfun;

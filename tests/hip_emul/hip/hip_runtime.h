@@ -19,9 +19,13 @@
 struct emul_dim3 { unsigned x = 1, y = 1, z = 1; };
 extern thread_local emul_dim3 threadIdx, blockIdx, blockDim, gridDim;
 // (thread_local: the emulated C ABI traces on several host threads at once, one per device slot)
+// rays_emul_redo_steps: how many rays the RK4 kernel handed over to rk4_resume_ray (rays_rk4_body.inc:
+// kStopResumeExact; emul_trace.cpp), so that a test can tell that a fixture exercises the hand-over
+#include <atomic>
+namespace rays { extern std::atomic<long long> rays_emul_redo_steps; }
 #define RAYS_EMUL_DEFINE_GLOBALS \
   thread_local emul_dim3 threadIdx, blockIdx, blockDim, gridDim; \
-  namespace rays { thread_local double lds[1 << 16]; }
+  namespace rays { thread_local double lds[1 << 16]; std::atomic<long long> rays_emul_redo_steps{0}; }
 
 #ifdef RAYS_EMUL_WAVE
 #include "hip_wave_emul.h"   // 64 lanes per wave as fibers: __any / __ballot / __shfl are real cross-lane operations

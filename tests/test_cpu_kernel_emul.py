@@ -204,3 +204,58 @@ def test_eqdsk_lin_interp_outermost_cells_are_memory_safe():
     for k in ("ray_vec", "residual", "npoints", "stop_code", "end_ray_vec"):
         np.testing.assert_array_equal(out[k], ora[k])
     assert (ora["npoints"] >= 1).all()
+
+
+def test_rk4_hand_over_of_ill_conditioned_steps_runs_and_changes_nothing():
+    """The tolerance kernels do not commit a step whose stage ran into dD/dw -> 0: the ray ends for them with an internal
+    stop code and rk4_resume_kernel (an exact translation unit) takes the step again and runs the ray to its end
+    (rays_rk4_body.inc: kStopResumeExact; rays_rk4.hpp: rk4_resume_ray).  On the host both arithmetics are the
+    reference's, so the whole fan must come out bit-identical to the oracle -- and the path must have RUN: every ray of
+    the cfg 2 fan ends in such a step.  (The GPU tier measures what it buys: tests/test_gpu_numerics_full_fans.py.)"""
+    import ctypes
+    from tests import oracle_lib
+    g, nml, p = load_golden("cfg2_solovev1024_rk4")
+    lib = emul_lib.lib()
+    lib.rays_emul_redo_steps.restype = ctypes.c_longlong
+    lib.rays_emul_redo_steps(1)
+    r0, n0 = g["rvec0_full"], g["rindex_vec0_full"]
+    out = emul_lib.trace(p, r0, n0)
+    n_handed = lib.rays_emul_redo_steps(1)
+    ora = oracle_lib.trace(p, r0, n0, nthreads=8)
+    for k in ("npoints", "stop_code", "ray_vec", "residual", "end_ray_vec", "end_residuals", "max_residuals"):
+        np.testing.assert_array_equal(out[k], ora[k], err_msg=k)
+    assert (out["stop_code"] < 1000).all(), "the internal hand-over code leaked"
+    assert 0.5 * len(r0) < n_handed <= len(r0), f"{n_handed} of {len(r0)} rays handed over"
+    print(f"rays handed over to rk4_resume_ray: {n_handed} of {len(r0)}")
+
+
+def test_rk4_resume_traces_whole_rays_like_the_reference(tmp_path):
+    """rk4_resume_ray (what rk4_resume_kernel runs) is a third statement of trace_rays' loop (after the kernels' state
+    machine and the oracle).  Built with a hand-over ratio of 2 every step's last stage "collapses", so every ray is handed
+    over at its FIRST step and the resume code traces it from point 1 to its end: all seven result arrays must be the
+    oracle's, bit for bit -- Solovev fan (rays ending at the mode coalescence, in the box wall, at nstep_max), a slab
+    fixture with damping rows (nv = 8), and a fused `ds` scan's per-run steps."""
+    import ctypes
+    from tests import oracle_lib
+    out_lib = str(tmp_path / "librays_emul_handover_all.so")
+    emul_lib.build(out=out_lib, defs=["-DRAYS_RK4_HANDOVER_RATIO=2.0"])
+    saved = emul_lib._lib
+    emul_lib._lib = emul_lib._load(out_lib)
+    try:
+        lib = emul_lib._lib
+        lib.rays_emul_redo_steps.restype = ctypes.c_longlong
+        for name, take in (("cfg2_solovev1024_rk4", slice(0, 1024, 8)), ("gold_slab16_damp_rk4", slice(None)),
+                           ("gold_solovev_evanescent_rk4", slice(None))):
+            g, nml, p = load_golden(name)
+            r0 = g["rvec0_full"][take] if "rvec0_full" in g.files else g["rvec0"][take]
+            n0 = g["rindex_vec0_full"][take] if "rindex_vec0_full" in g.files else g["rindex_vec0"][take]
+            lib.rays_emul_redo_steps(1)
+            out = emul_lib.trace(p, r0, n0)
+            handed = lib.rays_emul_redo_steps(1)
+            ora = oracle_lib.trace(p, r0, n0, nthreads=8)
+            for k in ("npoints", "stop_code", "ray_vec", "residual", "end_ray_vec", "end_residuals", "max_residuals"):
+                np.testing.assert_array_equal(out[k], ora[k], err_msg=f"{name}: {k}")
+            started = int((ora["npoints"] > 1).sum())
+            assert handed >= started, f"{name}: {handed} rays handed over, {started} take at least one step"
+    finally:
+        emul_lib._lib = saved

@@ -26,12 +26,15 @@ pytestmark = pytest.mark.gpu
 # config, ray stride, states per restart call (below / from 131072: the one-wave / two-waves build, as the fan dispatches)
 FANS = [("cfg3b_solovev64k_rk4.in", 1, 65536), ("cfg5b_axisym256k_rk4_damp.in", 1, 65536), ("cfg4_slab1M_rk4.in", 16, 262144)]
 
-# Bounds of the tolerance flavour, per config: (steps above 1e-10, max per step, max pointwise).  Measured values are in
-# profiles/numerics_evidence.json; the bounds leave a factor ~2 for another compiler's instruction selection.
+# Bounds of the tolerance flavour, per config: steps above 1e-10 (north_star's bar: none), max per step, max pointwise.
+# Measured (profiles/numerics_evidence.json): per step 5.1e-15 | 2.2e-16 | 3.5e-14, pointwise 1.1e-8 | 4.2e-15 | 2.3e-9.
+# Before the ill-conditioned steps were handed over to the reference's arithmetic (rays_rk4_body.inc: kStopResumeExact)
+# the headline fan had 13 steps above 1e-10, max 4.5e-10.  The per-step bounds leave two decades for another compiler's
+# instruction selection; the pointwise ones are regression alarms (accumulated deviation is not part of the per-step bar).
 BOUNDS = {
-    "cfg3b_solovev64k_rk4.in": dict(n_above=40, max_per_step=2e-9, max_pointwise=5e-8),
-    "cfg5b_axisym256k_rk4_damp.in": dict(n_above=0, max_per_step=1e-10, max_pointwise=1e-9),
-    "cfg4_slab1M_rk4.in": dict(n_above=0, max_per_step=1e-10, max_pointwise=1e-6),
+    "cfg3b_solovev64k_rk4.in": dict(n_above=0, max_per_step=1e-12, max_pointwise=5e-8),
+    "cfg5b_axisym256k_rk4_damp.in": dict(n_above=0, max_per_step=1e-13, max_pointwise=1e-9),
+    "cfg4_slab1M_rk4.in": dict(n_above=0, max_per_step=1e-11, max_pointwise=1e-6),
 }
 
 

@@ -10,7 +10,7 @@ CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 BASE = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function",
         "-DRAYS_INST_FAST", "-Rpass-analysis=kernel-resource-usage", "-c", "rays_inst.hip", "-o", "/dev/null"]
 EXACT = ["-ffp-contract=off"]
-TOL = ["-ffp-contract=fast", "-fassociative-math", "-fno-signed-zeros", "-fno-trapping-math", "-DRAYS_TOL_FLAVOUR", "-DRAYS_INST_TOL=1"]
+TOL = ["-ffp-contract=fast-honor-pragmas", "-fassociative-math", "-fno-signed-zeros", "-fno-trapping-math", "-DRAYS_TOL_FLAVOUR", "-DRAYS_INST_TOL=1"]
 
 
 def group(solver, eq, deriv, ue, tol=False):
