@@ -3,6 +3,9 @@
 # sources where they lie under /root/reference into binaries under oracle/_ref/.
 #
 #   oracle/_ref/rays_ref_dump   reference initialize + trace_rays + raw-binary dump (CPU)
+#   oracle/_ref/solovev_2_eqdsk the reference's own tool that writes the g-eqdsk of a Solovev equilibrium
+#                               (RAYS_project/solovev_2_eqdsk/solovev_2_eqdsk.f90): BASELINE config 5's 129 x 129 file
+#                               is its output (oracle/make_cfg5_eqdsk.sh)
 #   oracle/_ref/rays_hip_dropin reference host (initialize/ray_results/...) with trace_rays
 #                               REPLACED by fortran/trace_rays_hip.f90, the three ray launchers by
 #                               fortran/{solovev,simple_slab,axisym_toroid}_ray_init_hip.f90 and the
@@ -21,6 +24,8 @@
 #   P5 drop the re-declaration of zfun0/zfun0_real_arg in damp_fund_ECH
 #   P6 cut the NetCDF writer/reader (I/O only) from ray_results_m / finalize_run
 #   P7 cut the 'multiple_mirror' equilibrium case (drags in NetCDF)
+#   P8 (solovev_2_eqdsk only) ask get_unit_number() for the unit BEFORE opening rays.in with it (the program opens
+#      an undefined unit number first and asks afterwards)
 # No statement on the hot path (trace_rays, ode, eqn_ray, equilibrium, deriv_*, check_save)
 # is touched.  No stand-in for NetCDF is written: the I/O code that needs it is removed.
 set -euo pipefail
@@ -109,6 +114,13 @@ LIBOBJS=$(for m in $MODS $EXTS; do echo "$m.o"; done)
 $FC $FFLAGS -c ray_tracing_ref.f90 -o ray_tracing_ref.o
 $FC $FFLAGS -cpp -c "$HERE/ref_dump_driver.f90" -o ref_dump_driver.o
 $FC $FFLAGS -o "$OUT/rays_ref_dump" ref_dump_driver.o ray_tracing_ref.o $LIBOBJS
+
+# ---- (1b) the reference's solovev_2_eqdsk (SURVEY 8(d) cfg 5: "eqdsk 129 x 129 written by solovev_2_eqdsk") -----------
+awk '/^ *open\(unit=input_unit, file=.rays.in./ { held = $0; next }
+     /^ *input_unit = get_unit_number\(\)/ && held != "" { print; print held; held = ""; next }
+     { print }' "$P/solovev_2_eqdsk/solovev_2_eqdsk.f90" > "$W/solovev_2_eqdsk.f90"                  # P8
+$FC $FFLAGS -c solovev_2_eqdsk.f90 -o solovev_2_eqdsk.o
+$FC $FFLAGS -o "$OUT/solovev_2_eqdsk" solovev_2_eqdsk.o $LIBOBJS
 
 # ---- (2) drop-in: same host objects, trace_rays replaced by the HIP shim --------------------
 LIBHIP=$ROOT/rays_amd/lib/librays_hip.so

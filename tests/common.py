@@ -21,6 +21,7 @@ GOLDEN_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_n
                 "gold_axisym64_solmag_damp_rk4", "gold_axisym64_solmag_sg_num",
                 "gold_axisym64_solmag_splines_grad_rk4",
                 "gold_axisym64_eqlin_damp_rk4", "gold_axisym64_eqlin_tspline_sg_num",
+                "gold_axisym64_eqdsk129_tspline_damp_rk4", "gold_axisym64_eqdsk129_tspline_damp_sg",
                 "gold_slab_one_ray_rk4", "gold_solovev_file_rays_damp_rk4"]
 
 # launchers that take single rays by position and direction: host-side in every build (the reference's own routine under

@@ -11,9 +11,11 @@ what the tests read.
     python tests/golden/make_golden.py --check                 regenerate everything into a scratch directory and
                                                                compare it with the committed files bit for bit
 
-The host-side spline tables next to the eqdsk file (configs/solovev_65x65.geqdsk.tables.npz, read by the Python
-host) are the UNION of what the eqdsk cases dump (each case's namelist selects its own profile splines: ne_* in
-one, te_* / ti_* in another); overlapping entries must agree bit for bit.
+The host-side spline tables next to an eqdsk file (configs/<file>.geqdsk.tables.npz, read by the Python host) are the
+UNION of what the cases on that file dump (each case's namelist selects its own profile splines: ne_* in one,
+te_* / ti_* in another); overlapping entries must agree bit for bit.  Two files: solovev_65x65.geqdsk (written by
+tools/make_solovev_eqdsk.py) and solovev_129x129.geqdsk (BASELINE config 5's, written by the REFERENCE's own
+solovev_2_eqdsk: oracle/make_cfg5_eqdsk.sh).
 """
 import os
 import shutil
@@ -84,6 +86,10 @@ CASES = [
     ("gold_axisym64_solmag_damp_rk4", "gold_axisym64_solmag_damp_rk4.in", list(range(0, 64, 5)), 10, 60),
     ("gold_axisym64_solmag_sg_num", "gold_axisym64_solmag_sg_num.in", list(range(0, 64, 7)), 0, 0),
     ("gold_axisym64_solmag_splines_grad_rk4", "gold_axisym64_solmag_splines_grad_rk4.in", list(range(0, 64, 9)), 25, 0),
+    # BASELINE config 5 / 5b as SURVEY 8(d) wrote it, 8 x 8 rays: the 129 x 129 g-eqdsk written by the reference's own
+    # solovev_2_eqdsk (oracle/make_cfg5_eqdsk.sh), splined n, Te and Ti, ECH damping; RK4 and Shampine-Gordon
+    ("gold_axisym64_eqdsk129_tspline_damp_rk4", "gold_axisym64_eqdsk129_tspline_damp_rk4.in", list(range(0, 64, 5)), 10, 60),
+    ("gold_axisym64_eqdsk129_tspline_damp_sg", "gold_axisym64_eqdsk129_tspline_damp_sg.in", list(range(0, 64, 5)), 0, 0),
     ("gold_axisym64_eqlin_damp_rk4", "gold_axisym64_eqlin_damp_rk4.in", list(range(0, 64, 5)), 10, 0),
     ("gold_axisym64_eqlin_tspline_sg_num", "gold_axisym64_eqlin_tspline_sg_num.in", list(range(0, 64, 7)), 0, 0),
     # launchers that take single rays by position and direction (host-side in every build: acos / cos of libm)
@@ -105,7 +111,21 @@ def check_deterministic(cfg):
                  "(the reference races otherwise and the fixture would not be reproducible)")
 
 
-TABLES = os.path.join("configs", "solovev_65x65.geqdsk.tables.npz")
+EQDSK_FILES = ("solovev_65x65.geqdsk", "solovev_129x129.geqdsk")
+
+
+def tables_path(eqdsk):
+    return os.path.join("configs", eqdsk + ".tables.npz")
+
+
+def eqdsk_of(cfg):
+    """the g-eqdsk file a namelist's spline magnetics read (None: another magnetics model)"""
+    from rays_amd.namelist import read_namelist
+    nml = read_namelist(os.path.join(ROOT, "configs", cfg))
+    f = str(nml.get("eqdsk_magnetics_spline_interp_list", {}).get("eqdsk_file_name", "")).strip()
+    return f or None
+
+
 LD_FIXTURE = os.path.join("tests", "golden", "run_results.gold_slab4_ld")
 DEP_LD_FIXTURE = os.path.join("tests", "golden", "deposition_profiles.gaxi")
 
@@ -211,7 +231,7 @@ def generate(out_root, only=()):
                 tabs = {k: np.asarray(v) for k, v in axi.items() if np.ndim(v) == 0 or np.size(v)}
                 if dep is not None and "rho_grid" in dep:   # rho(psiN) spline, for the Ptotal_rho profile
                     tabs.update(rho_grid=dep["rho_grid"], rho_fspl=dep["rho_fspl"])
-                merge_tables(host_tabs, tabs, name)
+                merge_tables(host_tabs.setdefault(eqdsk_of(cfg), {}), tabs, name)
         if dep is not None:
             # deposition profiles of the FULL fan + the full-fan trajectories they
             # are binned from (v(1:3), v(8)) so the device binner can be checked without a re-trace
@@ -233,14 +253,14 @@ def generate(out_root, only=()):
         np.savez_compressed(path, **out)
         print(f"{name}: nray={ref['nray']} kept={len(idx)} maxpts={keep} "
               f"steps={int((ref['npoints'] - 1).sum())} -> {os.path.getsize(path) / 1e3:.0f} kB")
-    if host_tabs:
-        dst = os.path.join(out_root, TABLES)
-        if only and os.path.exists(os.path.join(ROOT, TABLES)):
+    for eqdsk, tabs in host_tabs.items():
+        dst = os.path.join(out_root, tables_path(eqdsk))
+        if only and os.path.exists(os.path.join(ROOT, tables_path(eqdsk))):
             # a partial regeneration keeps what the cases not run contributed (same rule: overlaps must agree)
-            z = np.load(os.path.join(ROOT, TABLES))
-            merge_tables(host_tabs, {k: z[k] for k in z.files}, "committed " + TABLES)
-        np.savez_compressed(dst, **host_tabs)
-        print(f"{TABLES}: {sorted(host_tabs)}")
+            z = np.load(os.path.join(ROOT, tables_path(eqdsk)))
+            merge_tables(tabs, {k: z[k] for k in z.files}, "committed " + tables_path(eqdsk))
+        np.savez_compressed(dst, **tabs)
+        print(f"{tables_path(eqdsk)}: {sorted(tabs)}")
 
 
 def ld_records(path):
@@ -272,10 +292,11 @@ def check():
                 diffs.append(f"{name}: keys differ: only regenerated {sorted(set(a.files) - set(b.files))}, "
                              f"only committed {sorted(set(b.files) - set(a.files))}")
             diffs += [f"{name}: '{k}' differs" for k in sorted(set(a.files) & set(b.files)) if not same_bits(a[k], b[k])]
-        a, b = np.load(os.path.join(d, TABLES)), np.load(os.path.join(ROOT, TABLES))
-        if set(a.files) != set(b.files):
-            diffs.append(f"{TABLES}: keys differ: regenerated {sorted(a.files)}, committed {sorted(b.files)}")
-        diffs += [f"{TABLES}: '{k}' differs" for k in sorted(set(a.files) & set(b.files)) if not same_bits(a[k], b[k])]
+        for T in (tables_path(e) for e in EQDSK_FILES):
+            a, b = np.load(os.path.join(d, T)), np.load(os.path.join(ROOT, T))
+            if set(a.files) != set(b.files):
+                diffs.append(f"{T}: keys differ: regenerated {sorted(a.files)}, committed {sorted(b.files)}")
+            diffs += [f"{T}: '{k}' differs" for k in sorted(set(a.files) & set(b.files)) if not same_bits(a[k], b[k])]
         if ld_records(os.path.join(d, LD_FIXTURE)) != ld_records(os.path.join(ROOT, LD_FIXTURE)):
             diffs.append(f"{LD_FIXTURE}: differs beyond its date / wall-time records")
         if open(os.path.join(d, DEP_LD_FIXTURE)).read() != open(os.path.join(ROOT, DEP_LD_FIXTURE)).read():

@@ -143,7 +143,7 @@ def test_sg_lane_refill_matches_oracle(which):
             "ode_list": dict(nstep_max=5)})
         want = "sg_group_kernel<5, 2, 4>"
     else:
-        g, nml0, p0 = load_golden("gold_axisym64_eqdsk_damp_sg")   # hands the eqdsk spline tables to hip + oracle
+        g, nml0, p0 = load_golden("gold_axisym64_eqdsk129_tspline_damp_sg")   # hands cfg 5's eqdsk spline tables to hip + oracle
         tab = {k[4:]: (float(g[k]) if g[k].ndim == 0 else g[k]) for k in g.files if k.startswith("axi_")}
         p, r0, n0 = _fan("cfg5_axisym256k_sg_damp.in", {
             "axisym_toroid_ray_init_r_z_nphi_ntheta_list": dict(n_rindex_theta=32, n_rindex_phi=32,
@@ -206,7 +206,8 @@ def test_fused_scan_one_launch_matches_oracle():
 # (2.7e-8, 2.7e-10); with rays_libm.hpp (glibc's algorithms) every restarted step is bit-identical.
 PER_STEP_CASES = ["gold_slab_shear_gauss_3spec_sg_num", "gold_axisym64_eqdsk_tspline_rk4_num",
                   "gold_solovev64_sg_num", "gold_solovev64_arcl_grad_sg", "gold_solovev64_damp_sg",
-                  "gold_axisym64_eqdsk_damp_sg", "gold_solovev64_pow_rk4", "gold_solovev64_rk4_num"]
+                  "gold_axisym64_eqdsk_damp_sg", "gold_solovev64_pow_rk4", "gold_solovev64_rk4_num",
+                  "gold_axisym64_eqdsk129_tspline_damp_sg"]
 
 
 @pytest.mark.parametrize("name", PER_STEP_CASES)
@@ -243,7 +244,7 @@ def test_baseline_config_at_full_size_sampled_against_oracle(cfg, stride, kernel
     from rays_amd.trace import DeviceTrace
     tab = None
     if "axisym" in cfg:
-        g, _, _ = load_golden("gold_axisym64_eqdsk_damp_sg")
+        g, _, _ = load_golden("gold_axisym64_eqdsk129_tspline_damp_sg")   # cfg 5's equilibrium file and profile splines
         tab = {k[4:]: (float(g[k]) if g[k].ndim == 0 else g[k]) for k in g.files if k.startswith("axi_")}
     p, r0, n0 = _fan(cfg, {}, tables=tab)
     assert hip.kernel_name(p, len(r0)) == kernel
@@ -276,7 +277,7 @@ def test_ray_hand_out_order_changes_nothing(monkeypatch, cfg, overrides):
     from rays_amd.trace import DeviceTrace
     tab = None
     if "axisym" in cfg:
-        g, _, _ = load_golden("gold_axisym64_eqdsk_damp_sg")
+        g, _, _ = load_golden("gold_axisym64_eqdsk129_tspline_damp_sg")   # cfg 5's equilibrium file and profile splines
         tab = {k[4:]: (float(g[k]) if g[k].ndim == 0 else g[k]) for k in g.files if k.startswith("axi_")}
     p, r0, n0 = _fan(cfg, overrides, tables=tab)
     assert len(r0) > 65536 and "w2" not in hip.kernel_name(p, len(r0))   # more rays than the 65536 lanes of the launch

@@ -41,7 +41,8 @@ def _run(binary, cfg, d, extra_env=None):
                                  "gold_slab_lin2_rk4_num.in", "gold_slab_negative_dens_rk4.in",
                                  "gold_solovev64_slow_sg.in", "gold_axisym64_solmag_damp_rk4.in",
                                  "gold_axisym64_solmag_splines_grad_rk4.in", "gold_axisym64_eqlin_damp_rk4.in",
-                                 "gold_slab_one_ray_rk4.in", "gold_solovev_file_rays_damp_rk4.in"])
+                                 "gold_slab_one_ray_rk4.in", "gold_solovev_file_rays_damp_rk4.in",
+                                 "gold_axisym64_eqdsk129_tspline_damp_rk4.in", "gold_axisym64_eqdsk129_tspline_damp_sg.in"])
 def test_fortran_dropin_equals_reference_binary(cfg):
     with tempfile.TemporaryDirectory() as d:
         ref = _run(REF, cfg, os.path.join(d, "ref"))
@@ -59,7 +60,8 @@ def test_fortran_dropin_equals_reference_binary(cfg):
 @pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(HIPBIN)),
                     reason="reference binaries not built (oracle/build_ref.sh needs /root/reference)")
 @pytest.mark.parametrize("cfg", ["gold_axisym64_eqdsk_damp_rk4.in", "gold_slab16_damp_rk4.in",
-                                 "gold_axisym64_solmag_damp_rk4.in", "gold_axisym64_eqlin_damp_rk4.in"])
+                                 "gold_axisym64_solmag_damp_rk4.in", "gold_axisym64_eqlin_damp_rk4.in",
+                                 "gold_axisym64_eqdsk129_tspline_damp_rk4.in"])
 def test_fortran_deposition_dropin_equals_reference_post_processor(cfg):
     """fortran/deposition_profiles_hip.f90 (rays_hip_deposition on the ray_results_m arrays of the drop-in run)
     against the reference's calculate_deposition_profiles on the reference run: work(n_bins, nray), the profiles

@@ -23,11 +23,11 @@ RK4_CASES = ["cfg1_slab16_rk4", "cfg2_solovev1024_rk4", "gold_solovev64_rk4_num"
              "gold_slab_ns1_rk4", "gold_solovev64_damp_grad_rk4", "gold_solovev64_4spec_rk4_num",
              "gold_slab16_damp_multi_grad_rk4", "gold_axisym64_solmag_damp_rk4",
              "gold_axisym64_solmag_splines_grad_rk4", "gold_axisym64_eqlin_damp_rk4",
-             "gold_slab_one_ray_rk4", "gold_solovev_file_rays_damp_rk4"]
+             "gold_slab_one_ray_rk4", "gold_solovev_file_rays_damp_rk4", "gold_axisym64_eqdsk129_tspline_damp_rk4"]
 SG_CASES = ["gold_solovev64_sg_cold", "gold_solovev64_sg_num", "gold_solovev64_damp_sg", "gold_axisym64_eqdsk_damp_sg",
             "gold_solovev64_arcl_grad_sg", "gold_solovev64_slow_sg",
             "gold_slab_shear_gauss_3spec_sg_num", "gold_slab_6spec_sg", "gold_solovev64_damp_multi_sg",
-            "gold_axisym64_solmag_sg_num", "gold_axisym64_eqlin_tspline_sg_num"]
+            "gold_axisym64_solmag_sg_num", "gold_axisym64_eqlin_tspline_sg_num", "gold_axisym64_eqdsk129_tspline_damp_sg"]
 
 def test_bit_exact_bar_is_the_bar_applied():
     """A green GPU run must mean the bit-exact bars were applied.  The kernels carry their own exp / pow, so their

@@ -144,7 +144,7 @@ def test_full_fan_counts_are_exactly_the_oracles(cfg, overrides, kernel):
     reference): the flavour is only acceptable if not one count flips."""
     tab = None
     if "axisym" in cfg:
-        g, _, _ = load_golden("gold_axisym64_eqdsk_damp_sg")
+        g, _, _ = load_golden("gold_axisym64_eqdsk129_tspline_damp_sg")   # cfg 5's equilibrium file and profile splines
         tab = {k[4:]: (float(g[k]) if g[k].ndim == 0 else g[k]) for k in g.files if k.startswith("axi_")}
     p, r0, n0 = _fan(cfg, overrides, tables=tab)
     assert hip.kernel_name(p, len(r0)) == kernel
