@@ -650,7 +650,8 @@ def main():
         line.update(split)
         if other is not None:
             line.update(other)
-        if world == 1 and not args.no_host_entry and args.exchange == "gather":
+        host_bytes = 8.0 * (nv + 1) * (p.nstep_max + 1) * nray_total   # the caller's padded ray_results_m arrays
+        if world == 1 and not args.no_host_entry and args.exchange == "gather" and host_bytes <= 8e9:
             try:   # outside the timed region: the rate the reference's own call site sees, both flavours
                 del tr
                 torch.cuda.empty_cache()

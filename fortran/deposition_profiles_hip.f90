@@ -33,6 +33,7 @@
     integer(c_int32_t), allocatable :: np32(:)
     character(len=512) :: msg
     integer :: i, m, g
+    integer(c_int) :: rc
     logical :: found
 
     select case (trim(profile_name))
@@ -71,14 +72,21 @@
        stop 1
     end if
 
-    allocate(np32(number_of_rays))
-    np32 = npoints
-    if (rays_hip_deposition(p, which, int(n_bins, c_int), int(number_of_rays, c_int), ray_vec, np32, &
-         & initial_ray_power, work, profile) /= 0) then
+    ! If this process traced these rays itself (fortran/trace_rays_hip.f90), their trajectories still lie on the GPU(s)
+    ! that traced them: binned there, nothing is uploaded.  Otherwise (a post-processor that read the arrays from a
+    ! results file) the arrays go to the device: only points 1..maxval(npoints) of each ray cross PCIe.
+    rc = rays_hip_deposition_last(p, which, int(n_bins, c_int), int(number_of_rays, c_int), initial_ray_power, work, profile)
+    if (rc == RAYS_HIP_NO_KEPT_RESULT) then
+       allocate(np32(number_of_rays))
+       np32 = npoints
+       rc = rays_hip_deposition(p, which, int(n_bins, c_int), int(number_of_rays, c_int), ray_vec, np32, &
+            & initial_ray_power, work, profile)
+       deallocate(np32)
+    end if
+    if (rc /= 0) then
        call last_error_string(msg)
        write(0,*) 'deposition_profile_hip: ', trim(msg) ; stop 1
     end if
-    deallocate(np32)
 
     Q_sum = 0.
     do i = 1, n_bins          ! sum(profile), in order

@@ -11,6 +11,8 @@
     use, intrinsic :: iso_c_binding
     implicit none
 
+    integer(c_int), parameter :: RAYS_HIP_NO_KEPT_RESULT = 5   ! rays_hip_deposition_last: no device-resident image held
+
     integer(c_int), parameter :: RAYS_ABI_VERSION = 3
     integer, parameter :: RAYS_NS0 = 6   ! species_m nspec0 + 1
 
@@ -279,6 +281,22 @@
           integer(c_int32_t), intent(in) :: npoints(*)
           real(c_double), intent(inout) :: work(*), profile(*)
        end function rays_hip_deposition
+
+       ! The same profiles of the rays the LAST rays_hip_trace call traced, binned from the image that call left on
+       ! the device(s) (rays_hip_keep_last_result(1) before the trace): no trajectory upload.  Returns
+       ! RAYS_HIP_NO_KEPT_RESULT when no image of a trace with this nray / nv / nstep_max is held.
+       integer(c_int) function rays_hip_keep_last_result(on) bind(C, name='rays_hip_keep_last_result')
+          import :: c_int
+          integer(c_int), value :: on
+       end function rays_hip_keep_last_result
+       integer(c_int) function rays_hip_deposition_last(p, which, n_bins, nray, initial_ray_power, work, profile) &
+                    & bind(C, name='rays_hip_deposition_last')
+          import :: c_int, c_double, rays_params_t
+          type(rays_params_t), intent(in) :: p
+          integer(c_int), value :: which, n_bins, nray
+          real(c_double), intent(in) :: initial_ray_power(*)
+          real(c_double), intent(inout) :: work(*), profile(*)
+       end function rays_hip_deposition_last
 
        ! Replaces the serial launch loops of ray_init_m's launchers (solovev_ray_init_nphi_ntheta_m.f90:
        ! 60-198 etc.): fills rvec0(3,nray_max), rindex_vec0(3,nray_max), ray_pwr_wt(nray_max), nray.

@@ -96,6 +96,10 @@
     stop_code = 0
     ray_stop_flag = ''
 
+    ! the result's device image stays where it was traced, for a post-processing step of this process
+    ! (deposition_profiles_hip.f90: rays_hip_deposition_last) -- RAYS_P.f90:19-44 traces and post-processes in one go
+    rc = rays_hip_keep_last_result(1_c_int)
+
     rc = rays_hip_trace(p, int(nray, c_int), rvec0, rindex_vec0, ray_vec, residual, npoints, &
          & stop_code, end_ray_vec, end_residuals, max_residuals, elapsed)
     if (rc /= 0) then

@@ -424,6 +424,21 @@ int rays_hip_deposition_device(const rays_params_t* p, int which, int n_bins, in
 int rays_hip_deposition(const rays_params_t* p, int which, int n_bins, int nray, const double* ray_vec,
                         const int32_t* npoints, const double* initial_ray_power, double* work, double* profile);
 
+/* The same profiles WITHOUT handing the trajectories back: the reference's drivers trace and post-process in one
+ * process (RAYS_P.f90:19-44 -- trace_rays, then calculate_deposition_profiles on the same ray_results_m arrays,
+ * deposition_profiles_m.f90:228-292).  rays_hip_keep_last_result(1) makes every later rays_hip_trace call leave the
+ * device-resident image of its result (the padded ray_vec slabs and npoints of its blocks, on the devices that traced
+ * them) in place until the next rays_hip_trace call, rays_hip_keep_last_result(0) or rays_hip_finalize; returns the
+ * previous setting.  rays_hip_deposition_last bins that image: same arguments and results as rays_hip_deposition
+ * minus the two arrays, blocks binned in ray order with the running sums carried from block to block (bit-identical
+ * to the reference's ray-ordered sum for any number of blocks / devices).  Returns RAYS_HIP_NO_KEPT_RESULT (and
+ * changes nothing) when no image of a trace with this nray / nv / nstep_max is held -- e.g. a post-processor that read
+ * its arrays from a results file: call rays_hip_deposition then. */
+#define RAYS_HIP_NO_KEPT_RESULT 5
+int rays_hip_keep_last_result(int on);
+int rays_hip_deposition_last(const rays_params_t* p, int which, int n_bins, int nray, const double* initial_ray_power,
+                             double* work, double* profile);
+
 /* Diagnostic entry used by the parity tests: evaluates equilibrium + deriv_cold + deriv_num +
  * eqn_ray + check_save at n states on the current device (host pointers; nv must be 7, nspec 1|2).
  * cold7/num7[n][7] = dddx(3) dddk(3) dddw; dvds[n][7]; resid[n]; codes[n][4] = equilibrium err,

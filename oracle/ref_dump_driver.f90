@@ -7,7 +7,8 @@
 ! (omp_get_wtime around trace_rays only; SURVEY.md 8(d)).
 !
 ! Controlled by environment variables (the reference allows at most one argv = namelist file):
-!   RAYS_DUMP_FILE   output path (default ref_dump.bin); 'none' = no dump, timing only
+!   RAYS_DUMP_FILE   output path (default ref_dump.bin); 'none' = no dump, timing only;
+!                    'skip' = no trajectory dump, but the other dumps below (deposition profiles ...) are made
 !   RAYS_DUMP_PROBE  stride (in recorded points) for per-state probes of equilibrium,
 !                    deriv_cold, deriv_num, eqn_ray, check_save; 0/unset = no probes
 !   RAYS_DUMP_REPS   repeat trace_rays this many times for timing (default 1)
@@ -133,6 +134,7 @@ program ref_dump_driver
 
     if (trim(fname) == 'none') stop
 
+    if (trim(fname) /= 'skip') then
     open(newunit=u, file=trim(fname), access='stream', form='unformatted', status='replace')
     write(u) int(z'52415953'), 2, nray, nv, nstep_max, nspec, probe_stride, 0
     write(u) omgrf, k0, clight, eps0, ds, s_max, dispersion_resid_limit, wall
@@ -144,6 +146,7 @@ program ref_dump_driver
     write(u) ray_vec
     write(u) residual
     write(u) end_ray_vec
+    end if
 
     call get_environment_variable('RAYS_DUMP_ZFUN', sval, status=stat)
     if (stat == 0 .and. len_trim(sval) > 0) then   ! Z-function spline table (zfunctions_m)
@@ -255,7 +258,7 @@ program ref_dump_driver
     end if
 
     ! ---- optional per-state probes of the RHS pieces (unit parity for the restatement) ----
-    if (probe_stride > 0) then
+    if (probe_stride > 0 .and. trim(fname) /= 'skip') then
        allocate(v(nv), dvds(nv))
        nprobe = 0
        do iray = 1, nray
@@ -291,5 +294,5 @@ program ref_dump_driver
           end do
        end do
     end if
-    close(u)
+    if (trim(fname) /= 'skip') close(u)
 end program ref_dump_driver

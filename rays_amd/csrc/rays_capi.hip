@@ -494,8 +494,10 @@ int rays_hip_init_devices(int n, const int* device_ids) {
 static void release_cached_device_blocks();
 static void rccl_close_all();
 static void release_step_scratch();
+static void drop_kept_result();
 int rays_hip_finalize(void) {
   rccl_close_all();
+  drop_kept_result();
   std::lock_guard<std::mutex> lk(g_mu);
   for (int d = 0; d < 16; d++)
     if (g_ws[d].counters) {
@@ -986,6 +988,35 @@ static StagingBuffers* staging_for_slot(int dev, size_t nv, long long min_points
   return &sb;
 }
 
+// ---- the device-resident image of the last rays_hip_trace call (rays_hip_keep_last_result) -------------------------
+// The reference's drivers trace and then post-process in one process (RAYS_P.f90:19-44: trace_rays, then the
+// deposition profiles of the same ray_results_m arrays).  With the switch on, a block of rays_hip_trace leaves its
+// padded ray_vec slab and its npoints on the device it traced on instead of giving them back to the block cache, and
+// rays_hip_deposition_last bins them in place: the trajectories cross PCIe once (to the caller's arrays), never back.
+struct KeptBlock {
+  int slot = -1, device = -1, r0 = 0, r1 = 0;
+  double* d_ray_vec = nullptr;
+  int32_t* d_npoints = nullptr;
+};
+struct KeptResult {
+  bool keep = false;
+  int nray = 0, nv = 0, nstep_max = 0;
+  std::vector<KeptBlock> blocks;  // in ray order once complete
+} g_kept;
+static void drop_kept_result() {  // caller holds no lock
+  std::vector<KeptBlock> old;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    old.swap(g_kept.blocks);
+    g_kept.nray = 0;
+  }
+  for (const KeptBlock& b : old) {
+    (void)hipSetDevice(b.device);
+    cached_free(b.slot, b.d_ray_vec);
+    cached_free(b.slot, b.d_npoints);
+  }
+}
+
 // One device's share of rays_hip_trace: rays [r0, r1) -> contiguous slabs of the host arrays.
 static int trace_block_on_device(int slot, int dev, const rays_params_t* p, int r0, int r1, const double* rvec0,
                                  const double* rindex_vec0, double* ray_vec, double* residual,
@@ -1139,6 +1170,19 @@ static int trace_block_on_device(int slot, int dev, const rays_params_t* p, int 
     DEV_CHK(hipStreamSynchronize(st));
   } while (0);
   lap("summaries");
+  {
+    bool kept = false;
+    if (rc == 0) {
+      std::lock_guard<std::mutex> lk(g_mu);
+      if (g_kept.keep) {
+        KeptBlock b;
+        b.slot = slot; b.device = dev; b.r0 = r0; b.r1 = r1; b.d_ray_vec = d_rv; b.d_npoints = d_np;
+        g_kept.blocks.push_back(b);
+        kept = true;
+      }
+    }
+    if (kept) d_rv = nullptr, d_np = nullptr;  // (cached_free ignores null)
+  }
   cached_free(slot, d_r); cached_free(slot, d_n); cached_free(slot, d_rv); cached_free(slot, d_res); cached_free(slot, d_np);
   cached_free(slot, d_sc); cached_free(slot, d_ev); cached_free(slot, d_er); cached_free(slot, d_mr);
   if (own_stream) (void)hipStreamDestroy(st);
@@ -1187,6 +1231,7 @@ int rays_hip_trace(const rays_params_t* p, int nray, const double* rvec0, const 
       devs.swap(slots);
     }
   }
+  drop_kept_result();  // the image of an earlier call (if any) goes back to the block cache
   const auto t0 = std::chrono::steady_clock::now();
   const int G = (int)devs.size();
   // contiguous blocks, like the reference's OpenMP schedule(static) (ray_tracing.f90:62)
@@ -1205,11 +1250,33 @@ int rays_hip_trace(const rays_params_t* p, int nray, const double* rvec0, const 
   for (int g = 0; g < G; g++)
     if (rcs[g]) {
       g_err = errs[g];
+      drop_kept_result();
       return rcs[g];
     }
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_kept.keep) {
+      std::sort(g_kept.blocks.begin(), g_kept.blocks.end(), [](const KeptBlock& a, const KeptBlock& b) { return a.r0 < b.r0; });
+      g_kept.nray = nray;
+      g_kept.nv = p->nv;
+      g_kept.nstep_max = p->nstep_max;
+    }
+  }
   if (elapsed_s)
     *elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return 0;
+}
+
+int rays_hip_keep_last_result(int on) {
+  if (std::getenv("RAYS_HIP_NO_KEEP_LAST_RESULT")) on = 0;  // measurement switch: A/B against the host-array path
+  bool was;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    was = g_kept.keep;
+    g_kept.keep = on != 0;
+  }
+  if (!on) drop_kept_result();
+  return was ? 1 : 0;
 }
 
 int rays_hip_pack_device(int nray, int nv, int nstep_max, const int32_t* d_npoints,
@@ -1331,6 +1398,8 @@ int rays_hip_deposition(const rays_params_t* p, int which, int n_bins, int nray,
   int maxnp = 1;
   for (int i = 0; i < nray; i++) maxnp = std::max(maxnp, (int)npoints[i]);
   if ((size_t)maxnp > npt) return fail("rays_hip_deposition: npoints exceeds nstep_max + 1");
+  const bool timing = std::getenv("RAYS_HIP_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   rays_params_t q = *p;
   q.nstep_max = maxnp - 1;  // the device copy holds maxnp points per ray
   double *d_rv = nullptr, *d_pw = nullptr, *d_work = nullptr, *d_prof = nullptr;
@@ -1362,6 +1431,71 @@ int rays_hip_deposition(const rays_params_t* p, int which, int n_bins, int nray,
   }
 #undef DEP_TRY
   release();
+  if (timing)
+    std::fprintf(stderr, "[rays_hip_deposition] %d rays, %.1f MB of trajectories uploaded: %.2f ms\n", nray,
+                 1e-6 * sizeof(double) * nv * (double)maxnp * (double)nray,
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  return 0;
+}
+
+// The deposition profiles of the rays the last rays_hip_trace call traced, binned where they lie (see KeptResult).
+// Blocks are binned in ray order, each continuing the running sums of the one before it (rays_hip_deposition_device's
+// d_profile_in): the profile is the reference's ray-ordered sum bit for bit, whatever the number of blocks / devices.
+int rays_hip_deposition_last(const rays_params_t* p, int which, int n_bins, int nray, const double* initial_ray_power,
+                             double* work, double* profile) {
+  int rc = rays_hip_check_params(p);
+  if (rc) return rc;
+  if (n_bins < 1 || nray < 0 || !initial_ray_power || !profile) return fail("rays_hip_deposition_last: bad argument");
+  std::vector<KeptBlock> blocks;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_kept.keep || g_kept.blocks.empty() || g_kept.nray != nray || g_kept.nv != p->nv || g_kept.nstep_max != p->nstep_max) {
+      g_err = "rays_hip_deposition_last: no device-resident result of a rays_hip_trace call with this shape "
+              "(rays_hip_keep_last_result(1) before the trace; same nray, nv, nstep_max)";
+      return RAYS_HIP_NO_KEPT_RESULT;
+    }
+    blocks = g_kept.blocks;
+  }
+  const bool timing = std::getenv("RAYS_HIP_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<double> carry((size_t)n_bins, 0.0), wbuf;
+  bool have_carry = false;
+  for (const KeptBlock& b : blocks) {
+    const int n = b.r1 - b.r0;
+    if (n <= 0) continue;
+    HIP_TRY(hipSetDevice(b.device));
+    double *d_pw = nullptr, *d_work = nullptr, *d_in = nullptr, *d_out = nullptr;
+    auto release = [&]() { (void)hipFree(d_pw); (void)hipFree(d_work); (void)hipFree(d_in); (void)hipFree(d_out); };
+#define DEPL_TRY(call)                                               \
+  do {                                                               \
+    hipError_t e_ = (call);                                          \
+    if (e_ != hipSuccess) { release(); return hip_fail(e_, #call); } \
+  } while (0)
+    DEPL_TRY(hipMalloc(&d_pw, sizeof(double) * (size_t)n));
+    DEPL_TRY(hipMalloc(&d_work, sizeof(double) * (size_t)n_bins * (size_t)n));
+    DEPL_TRY(hipMalloc(&d_in, sizeof(double) * (size_t)n_bins));
+    DEPL_TRY(hipMalloc(&d_out, sizeof(double) * (size_t)n_bins));
+    DEPL_TRY(hipMemcpy(d_pw, initial_ray_power + b.r0, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    if (have_carry) DEPL_TRY(hipMemcpy(d_in, carry.data(), sizeof(double) * (size_t)n_bins, hipMemcpyHostToDevice));
+    rc = rays_hip_deposition_device(p, which, n_bins, n, b.d_ray_vec, b.d_npoints, d_pw, d_work, have_carry ? d_in : nullptr,
+                                    d_out, nullptr);
+    if (rc) { release(); return rc; }
+    DEPL_TRY(hipDeviceSynchronize());
+    DEPL_TRY(hipMemcpy(carry.data(), d_out, sizeof(double) * (size_t)n_bins, hipMemcpyDeviceToHost));
+    have_carry = true;
+    if (work) {  // device: [n_bins][n]  ->  reference work(n_bins, nray) = C [nray][n_bins]
+      wbuf.resize((size_t)n_bins * (size_t)n);
+      DEPL_TRY(hipMemcpy(wbuf.data(), d_work, sizeof(double) * wbuf.size(), hipMemcpyDeviceToHost));
+      for (int r = 0; r < n; r++)
+        for (int bb = 0; bb < n_bins; bb++) work[(size_t)(b.r0 + r) * n_bins + bb] = wbuf[(size_t)bb * n + r];
+    }
+#undef DEPL_TRY
+    release();
+  }
+  std::memcpy(profile, carry.data(), sizeof(double) * (size_t)n_bins);
+  if (timing)
+    std::fprintf(stderr, "[rays_hip_deposition_last] %d rays in %zu device-resident block(s), no trajectory upload: %.2f ms\n",
+                 nray, blocks.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   return 0;
 }
 

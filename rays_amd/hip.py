@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = (
     "rays_hip_kernel_name", "rays_hip_kernel_name_for", "rays_hip_probe", "rays_hip_pack_device", "rays_hip_unpack_device",
     "rays_hip_sizeof_fan", "rays_hip_ray_init", "rays_hip_ray_init_device",
     "rays_hip_set_rho_table", "rays_hip_deposition_device", "rays_hip_deposition",
+    "rays_hip_keep_last_result", "rays_hip_deposition_last",
     "rays_hip_set_numerics", "rays_hip_get_numerics",
 )
 
@@ -117,6 +118,10 @@ def load():
     lib.rays_hip_deposition.argtypes = [pp, C.c_int, C.c_int, C.c_int, dp, ip, dp, dp, dp]
     lib.rays_hip_deposition_device.restype = C.c_int
     lib.rays_hip_deposition_device.argtypes = [pp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    lib.rays_hip_keep_last_result.restype = C.c_int
+    lib.rays_hip_keep_last_result.argtypes = [C.c_int]
+    lib.rays_hip_deposition_last.restype = C.c_int
+    lib.rays_hip_deposition_last.argtypes = [pp, C.c_int, C.c_int, C.c_int, dp, dp, dp]
     lib.rays_hip_set_numerics.restype = C.c_int
     lib.rays_hip_set_numerics.argtypes = [C.c_int]
     lib.rays_hip_get_numerics.restype = C.c_int
@@ -265,6 +270,31 @@ def deposition_host(p: RaysParams, which: str, n_bins: int, ray_vec, npoints, in
     work, prof = np.zeros((nray, n_bins)), np.zeros(n_bins)
     _check(load().rays_hip_deposition(C.byref(p), DEP_PROFILES[which], int(n_bins), nray, _dp(ray_vec), _ip(npoints),
                                       _dp(power), _dp(work), _dp(prof)), "rays_hip_deposition")
+    return work, prof
+
+
+NO_KEPT_RESULT = 5   # RAYS_HIP_NO_KEPT_RESULT
+
+
+def keep_last_result(on: bool) -> bool:
+    """rays_hip_keep_last_result: later trace_host calls leave their result's device image in place for
+    deposition_last (until the next trace_host / keep_last_result(False)).  Returns the previous setting."""
+    return bool(load().rays_hip_keep_last_result(1 if on else 0))
+
+
+def deposition_last(p: RaysParams, which: str, n_bins: int, initial_ray_power, want_work: bool = True):
+    """rays_hip_deposition_last: the profiles of the rays the last trace_host call traced, binned on the device(s) that
+    hold them (no trajectory upload).  Returns (work[nray][n_bins] or None, profile[n_bins]), or None when no such
+    image is held."""
+    power = np.ascontiguousarray(initial_ray_power, dtype=np.float64)
+    nray = len(power)
+    work = np.zeros((nray, n_bins)) if want_work else None
+    prof = np.zeros(n_bins)
+    rc = load().rays_hip_deposition_last(C.byref(p), DEP_PROFILES[which], int(n_bins), nray, _dp(power),
+                                         _dp(work) if want_work else None, _dp(prof))
+    if rc == NO_KEPT_RESULT:
+        return None
+    _check(rc, "rays_hip_deposition_last")
     return work, prof
 
 

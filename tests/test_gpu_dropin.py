@@ -28,7 +28,9 @@ def _run(binary, cfg, d, extra_env=None):
         if f.endswith(".geqdsk") or f.startswith("ray_init_"):   # (file_input_ray_init reads ray_init_<run_label>.in)
             shutil.copy(os.path.join(ROOT, "configs", f), d)
     env = dict(os.environ, RAYS_DUMP_FILE="dump.bin", RAYS_DUMP_PROBE="0", **(extra_env or {}))
-    subprocess.run([binary], cwd=d, env=env, check=True, stdout=subprocess.DEVNULL, timeout=600)
+    r = subprocess.run([binary], cwd=d, env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                       timeout=600)
+    _run.last_stderr = r.stderr
     return read_dump(os.path.join(d, "dump.bin"))
 
 
@@ -70,7 +72,13 @@ def test_fortran_deposition_dropin_equals_reference_post_processor(cfg):
     outs, files = {}, {}
     for tag, binary in (("ref", REF), ("hip", HIPBIN)):
         with tempfile.TemporaryDirectory() as d:
-            _run(binary, cfg, d, extra_env={"RAYS_DUMP_DEPOSITION": "dep.bin", "RAYS_DUMP_DEPOSITION_LD": "1"})
+            _run(binary, cfg, d, extra_env={"RAYS_DUMP_DEPOSITION": "dep.bin", "RAYS_DUMP_DEPOSITION_LD": "1",
+                                            "RAYS_HIP_TIMING": "1"})
+            if tag == "hip":
+                # trace -> profiles in one process (RAYS_P.f90:19-44): binned from the image rays_hip_trace left on the
+                # device (rays_hip_deposition_last), the trajectories are never uploaded again
+                assert "[rays_hip_deposition_last]" in _run.last_stderr and "no trajectory upload" in _run.last_stderr, \
+                    _run.last_stderr[-800:]
             outs[tag] = read_deposition(os.path.join(d, "dep.bin"))
             # the profile file post_process_RAYS / graphics_RAYS read, written by the REFERENCE's own
             # write_deposition_profiles_LD (deposition_profiles_m.f90:296-331) from the reference's sums / the GPU's

@@ -243,3 +243,33 @@ def test_result_files_equal_reference(tmp_path):
     nc = R.read_results_NC(str(tmp_path / "run_results.ld4.nc"))
     np.testing.assert_array_equal(nc["ray_vec"], ref["ray_vec"])
     np.testing.assert_array_equal(nc["npoints"], ref["npoints"])
+
+
+def test_deposition_of_the_last_trace_from_its_device_image():
+    """rays_hip_keep_last_result + rays_hip_deposition_last: the profiles of the rays rays_hip_trace has just traced,
+    binned from the slabs that call left on the device, against rays_hip_deposition on the host arrays of the same call
+    (itself bit-identical to the reference post-processor) -- several blocks per device, so the running sums are carried
+    from block to block; and the refusals: nothing held, another shape."""
+    g, nml, p = load_golden("gold_axisym64_eqdsk_damp_rk4")
+    r0, n0 = g["rvec0_full"], g["rindex_vec0_full"]
+    power, nb = g["dep_power"], int(g["dep_n_bins"])
+    hip.keep_last_result(False)
+    assert hip.deposition_last(p, "Ptotal_psi", nb, power) is None          # nothing held
+    prev = hip.keep_last_result(True)
+    try:
+        hip.init_devices([0, 0, 0])                                         # three blocks on the one device
+        out = hip.trace_host(p, r0, n0, ngpu=None)
+        np.testing.assert_array_equal(out["npoints"], g["npoints_full"])
+        for which in ("Ptotal_psi", "Ptotal_rho"):
+            if which == "Ptotal_rho":
+                hip.set_rho_table(g["dep_rho_grid"], g["dep_rho_fspl"])
+            w_host, prof_host = hip.deposition_host(p, which, nb, out["ray_vec"], out["npoints"], power)
+            w_dev, prof_dev = hip.deposition_last(p, which, nb, power)
+            np.testing.assert_array_equal(prof_dev, prof_host)
+            np.testing.assert_array_equal(w_dev, w_host)
+            i = list(g["dep_names"]).index(which)
+            np.testing.assert_array_equal(prof_dev, g["dep_profile"][i])   # = the reference post-processor's
+        assert hip.deposition_last(p, "Ptotal_psi", nb, power[:-1]) is None  # another nray: refused, not misread
+    finally:
+        hip.keep_last_result(prev)
+        hip.load().rays_hip_init(1)
