@@ -237,6 +237,8 @@
           integer(c_int), value :: flags
        end function rays_hip_scan_device
 
+       ! ASYNCHRONOUS on hip_stream (blocking before round 3): synchronise the stream before d_v1 / d_resid /
+       ! d_stop_code are read on the host or from another stream; one caller thread per (device, stream).
        integer(c_int) function rays_hip_ode_step_device(p, n, d_v0, d_s0, d_v1, d_resid, d_stop_code, hip_stream) &
                     & bind(C, name='rays_hip_ode_step_device')
           import :: c_int, c_ptr, rays_params_t

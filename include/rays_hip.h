@@ -302,8 +302,12 @@ int rays_hip_scan_device(const rays_params_t* p, int n_runs, const double* d_ds_
  * state.  Otherwise v1 is what ode_solver left in v: the advanced state when check_save refused the step
  * (ray_tracing.f90:214-234), v0 when the solver itself stopped (RK4_ode_m.f90:83-89), zeros when v0 already failed
  * the initial check_save (such a ray never starts: ray_tracing.f90:100-112) -- a recorded trajectory point always
- * passes it.  Asynchronous on hip_stream like rays_hip_trace_device; its scratch (one block per device and stream)
- * is kept between calls and released by rays_hip_finalize. */
+ * passes it.  ASYNCHRONOUS on hip_stream like rays_hip_trace_device (it was blocking before round 3): synchronise the
+ * stream -- hipStreamSynchronize, or hipDeviceSynchronize for the null stream -- before reading d_v1 / d_resid /
+ * d_stop_code on the host or from another stream.  Its scratch (one block per device and stream) is kept between
+ * calls and released by rays_hip_finalize; ONE caller thread per (device, stream): a second thread that asks the same
+ * stream for a larger block frees the first one's behind hipStreamSynchronize, which does not cover work the first
+ * thread has not enqueued yet. */
 int rays_hip_ode_step_device(const rays_params_t* p, int n, const double* d_v0, const double* d_s0,
                              double* d_v1, double* d_resid, int32_t* d_stop_code, void* hip_stream);
 

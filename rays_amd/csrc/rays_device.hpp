@@ -102,6 +102,9 @@ struct DevParams {
       inv_omgrf2_m;
   double inv_ms[RAYS_NS0], inv_eps0ms[RAYS_NS0];
   double inv_rk, inv_rk2, inv_rmaj, inv_rmaj2, inv_psiB;
+  // tolerance flavour (rays_device_arith.inc: RAYS_TOL_FLAVOUR): gamma_s = |B| * gam_per_b[s], alpha_s = n_s * alp_per_n[s]
+  // (equilibrium_m.f90:262-265 with the constant quotients folded on the host)
+  double gam_per_b[RAYS_NS0], alp_per_n[RAYS_NS0];
 };
 }  // namespace dev_types
 using dev_types::DevParams;
@@ -141,6 +144,10 @@ RAYS_DEV void hot_params(const DevParams& P, DevParams& H) {
     H.inv_eps0ms[is] = in_vgpr(P.inv_eps0ms[is]);
     H.n0s[is] = in_vgpr(P.n0s[is]);
     H.t0s[is] = in_vgpr(P.t0s[is]);
+#ifdef RAYS_TOL_FLAVOUR
+    H.gam_per_b[is] = in_vgpr(P.gam_per_b[is]);
+    H.alp_per_n[is] = in_vgpr(P.alp_per_n[is]);
+#endif
   }
 }
 

@@ -50,10 +50,12 @@ def load():
     # first serves the whole process; loaded in the other order -- this library (and with it /opt/rocm's runtime)
     # first, torch afterwards -- the second runtime to initialise finds "no ROCm-capable device".  The Python host
     # uses torch for device memory and streams (DeviceTrace, ode_step, bench.py), so torch goes first, always.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # A host that needs the C ABI alone (no DeviceTrace / ode_step / bench) sets RAYS_AMD_NO_TORCH=1 and saves the import.
+    if "torch" in __import__("sys").modules or not os.environ.get("RAYS_AMD_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise RaysHipError(
             f"{LIB_PATH} not found: build it with `make -C rays_amd/csrc` (needs hipcc, gfx950). "

@@ -79,6 +79,10 @@ static int run_rk4_waves(const rays::DevParams& D, const rays::TraceArgs& A, int
     if (g_rk4_w2_body) wave_emul::run_wave(0u, [&] { rays::rk4_trace_kernel_w2<EQ, NS, 0, NV>(D, A); }, threadIdx);
     else wave_emul::run_wave(0u, [&] { rays::rk4_trace_kernel<EQ, NS, 0, NV>(D, A); }, threadIdx);
   }
+  // what rays_capi.hip launches behind a tolerance kernel (this build hands ill-conditioned steps over like one:
+  // emul_trace.cpp defines RAYS_EMUL_HANDOVER): rk4_resume_kernel for the rays that came back with the internal stop code
+  for (int ray = 0; ray < A.nray; ray++)
+    if (A.stop_code[ray] == rays::kStopResumeExact) rays::rk4_resume_ray<EQ, NS, 0, NV>(D, A, ray);
   return 0;
 }
 extern "C" void rays_emul_rk4_waves_use_w2_body(int on) { g_rk4_w2_body = on; }

@@ -26,5 +26,5 @@ except Exception as e:
     print("$t: no summary:", e)
 PY
 done | tee $O/profile_overview.txt
-( bash tools/rehearse_multi_gpu.sh > $O/rehearse.log 2>&1; cp gpurun_out/rehearse/rehearse_n*.txt $O/ 2>/dev/null; tail -2 $O/rehearse.log )
+[ -n "$REHEARSE" ] && ( bash tools/rehearse_multi_gpu.sh > $O/rehearse.log 2>&1; cp gpurun_out/rehearse/rehearse_n*.txt $O/ 2>/dev/null; tail -2 $O/rehearse.log )
 python tools/kernel_resources_all.py > $O/kernel_resources.txt 2> $O/kernel_resources.err; tail -3 $O/kernel_resources.txt
