@@ -645,7 +645,9 @@ def main():
                                       "traffic / roofline_fp64 counters replayed from profiles/counters.json (rocprofv3 --pmc passes of "
                                       "this command on these kernel sources); achieved, kernel_ms and frac are measured in this run"),
                          "note": "the contract's HBM figure; the path is bound by FP64 instruction issue "
-                                 "(roofline_fp64), not by HBM: DESIGN.md 4.5"},
+                                 "(roofline_fp64), not by HBM: DESIGN.md 4.5"
+                                 + ("; kernel_ms spans the launch = this kernel + rk4_resume_kernel behind it (the exact "
+                                    "twin's continuation of the handed-over rays, ~0.05 ms: DESIGN.md 4.6)" if is_tol_kernel else "")},
         }
         if fp64 is not None:
             line["roofline_fp64"] = fp64
