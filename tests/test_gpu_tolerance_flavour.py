@@ -231,3 +231,43 @@ def test_handed_over_steps_are_the_references_bit_for_bit():
     assert (out["stop_code"] < 1000).all(), "the internal hand-over stop code reached the caller"
     np.testing.assert_array_equal(out["npoints"], ora["npoints"])
     np.testing.assert_array_equal(out["stop_code"], ora["stop_code"])
+
+
+def test_hand_over_in_a_fused_scan_and_without_the_optional_summaries():
+    """The hand-over travels in the per-ray summaries and the resumed ray needs its own run's step: (i) a fused `ds` scan
+    (rays_hip_scan_device: five runs x 128 rays, ONE launch) under the tolerance flavour has the oracle's ray counts and
+    stop codes run by run, last points within 1e-10, and no internal stop code; (ii) a device trace WITHOUT the optional
+    end_ray_vec / end_residuals / max_residuals arrays (the library then lends its own) gives the same npoints, stop codes
+    and trajectories as one with them."""
+    import torch
+    from rays_amd.params import copy_params
+    from rays_amd.scan import RayScan, scan_values
+    from rays_amd.trace import DeviceTrace
+    g, nml, p = load_golden("cfg2_solovev1024_rk4")
+    r0, n0 = g["rvec0_full"][::8], g["rindex_vec0_full"][::8]
+    vals = scan_values("fixed_increment", 5, p_start=float(p.ds) * 0.5, p_incr=float(p.ds) * 0.25)
+    scan = RayScan(p, r0, n0, vals)
+    scan.launch()
+    for v, r in zip(vals, scan.results()):
+        q = copy_params(p)
+        q.ds = float(v)
+        ora = oracle_lib.trace(q, r0, n0)
+        np.testing.assert_array_equal(r.npoints, ora["npoints"], err_msg=f"ds={v}")
+        np.testing.assert_array_equal(r.stop_code, ora["stop_code"], err_msg=f"ds={v}")
+        assert (r.stop_code < 1000).all()
+        last = np.maximum(ora["npoints"] - 1, 0)
+        a, b = r.ray_vec[np.arange(len(last)), last], ora["ray_vec"][np.arange(len(last)), last]
+        assert np.abs(a[:, :6] - b[:, :6]).max() <= 1e-6 * np.abs(b[:, :6]).max()
+    # (ii)
+    tr = DeviceTrace(p, r0, n0)
+    tr.launch()
+    torch.cuda.synchronize()
+    rv = torch.zeros_like(tr.ray_vec)
+    res = torch.zeros_like(tr.residual)
+    npts = torch.zeros_like(tr.npoints)
+    sc = torch.zeros_like(tr.stop_code)
+    hip.trace_device(p, len(r0), tr.rvec0.data_ptr(), tr.rindex_vec0.data_ptr(), rv.data_ptr(), res.data_ptr(), npts.data_ptr(),
+                     sc.data_ptr(), 0, 0, 0, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(npts, tr.npoints) and torch.equal(sc, tr.stop_code) and (sc < 1000).all()
+    assert torch.equal(rv, tr.ray_vec) and torch.equal(res, tr.residual)
