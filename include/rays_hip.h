@@ -230,11 +230,19 @@ int rays_hip_set_eqdsk_lin_tables(const rays_axisym_tables_t* t, double dR, doub
 /* Numerics of the trace kernels (process-wide; read when a trace is launched).
  *   RAYS_NUMERICS_EXACT (default): IEEE binary64 in the reference's operation order, no FMA contraction,
  *     correctly rounded quotients and roots -- trajectories bit-identical to the reference CPU path.
- *   RAYS_NUMERICS_TOLERANCE: the bar BASELINE.json's north_star states -- every step within 1e-10 relative of the
- *     reference's, ray counts / step indices / stop flags exactly the reference's -- which lets the kernels fuse
- *     a*b+c and use once-refined reciprocals and roots.  Built for ode_solver = RK4 with ray_deriv = cold (without
+ *   RAYS_NUMERICS_TOLERANCE: NOT bit-identical -- the kernels fuse a*b+c, re-associate, use once-refined reciprocals
+ *     and roots and algebraic short cuts.  What it is was measured on the full BASELINE fans against the reference
+ *     (tests/test_gpu_numerics_full_fans.py, profiles/numerics_evidence.json): restarted from every recorded reference
+ *     point, every step lands within 1e-10 relative (norm-wise on r and k) of the reference's next point -- the bar of
+ *     BASELINE.json's north_star; measured 4.4e-15 over the headline fan's 12 873 661 steps, 1e-12 over 32.8 M steps of
+ *     the slab fan -- and ray counts / step indices / stop flags are exactly the reference's on every ray surveyed;
+ *     ACCUMULATED along a ray the trajectory deviates by up to 1.6e-8.  The steps where that bar cannot hold for any
+ *     arithmetic but the reference's own (a ray's last recorded step before two modes coalesce) are handed over to a
+ *     kernel of the exact build.  Built for ode_solver = RK4 with ray_deriv = cold (without
  *     multi_spec_damping); every other configuration runs its exact kernel under either setting (finite-difference
- *     dD amplifies an ulp by 1e8, and the adaptive solver then takes another step sequence).
+ *     dD amplifies an ulp by 1e8, and the adaptive solver then takes another step sequence).  Fans of 131072 rays and
+ *     more run a two-waves-per-SIMD build without the hand-over: on Solovev fans that large a ray's last recorded step
+ *     can deviate by up to 4.5e-10.
  * The environment variable RAYS_HIP_NUMERICS = exact | tolerance sets the initial value.  Returns the previous
  * setting, or -1 for an unknown mode. */
 enum { RAYS_NUMERICS_EXACT = 0, RAYS_NUMERICS_TOLERANCE = 1 };

@@ -146,9 +146,9 @@ NUMERICS = {"exact": 0, "tolerance": 1}
 
 
 def set_numerics(mode: str) -> str:
-    """rays_hip_set_numerics: "exact" (bit-identical to the reference CPU path; default) or "tolerance" (north_star's
-    bar: 1e-10 relative per step, exact ray counts / step indices / stop flags; cold RK4 kernels).  Returns the
-    previous setting."""
+    """rays_hip_set_numerics: "exact" (bit-identical to the reference CPU path; default) or "tolerance" (not
+    bit-identical: every step within 1e-10 relative of the reference's -- 4e-15 measured on the headline fan --, exact
+    ray counts / step indices / stop flags; cold RK4 kernels; include/rays_hip.h).  Returns the previous setting."""
     prev = load().rays_hip_set_numerics(NUMERICS[mode])
     if prev < 0:
         raise RaysHipError("rays_hip_set_numerics: " + last_error())

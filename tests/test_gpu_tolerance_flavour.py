@@ -1,13 +1,14 @@
 """GPU tier: the TOLERANCE flavour of the cold RK4 kernels (rays_hip_set_numerics(RAYS_NUMERICS_TOLERANCE):
-`rk4_trace_kernel[_w2]<EQ | 16, ...>`, FMA contraction + once-refined reciprocals and roots) against the bar
-BASELINE.json's north_star states -- every step within 1e-10 relative of the reference's, ray counts / step
-indices / stop flags EXACTLY the reference's:
+`rk4_trace_kernel[_w2]<EQ | 16, ...>`, FMA contraction + re-association + once-refined reciprocals and roots) on the
+fixtures and on the fans' ray counts; tests/test_gpu_numerics_full_fans.py surveys the full fans step by step:
 
   * per step: the flavour restarted from every recorded reference point of every RK4 / cold fixture for one output
     step (ode_solver + check_save) lands within 1e-10 (norm-wise on r and k) of the reference's next point;
   * counts: npoints and stop codes of the fixtures and of the FULL fans of BASELINE configs 2, 3b (the headline,
     65536 rays), 4 (131769 rays, two-waves build) and 5b (262144 rays) equal the oracle's on every ray;
-  * accumulated trajectories stay within 1e-6 of the reference's over a whole ray (not part of the contract --
+  * the hand-over of ill-conditioned steps to rk4_resume_kernel (rays_rk4_body.inc: kStopResumeExact): handed-over
+    steps land ON the reference's points, inside a fused scan too, and the internal stop code never reaches the caller;
+  * accumulated trajectories stay within 1e-6 of the reference's over a whole ray (not part of the per-step bar --
     errors of 1e-16 per step grow along rays that graze a cutoff -- but a regression alarm).
 
 Everything else (finite-difference dD, SG, multi_spec_damping) runs the exact kernels under either setting."""
