@@ -157,7 +157,7 @@ def numerics_text(flavour, is_tol_kernel, ev):
     return (base + f" on all {ev['rays_surveyed']} rays surveyed; restarted from every one of the oracle's {ev['steps_restarted']} "
             f"recorded points, {ev['n_above_1e-10']} steps land further than 1e-10 (relative, norm-wise on r and k) from the "
             f"reference's next point, max {ev['max_per_step']:.2e}; accumulated along the rays the traced fan deviates "
-            f"pointwise by up to {ev['max_pointwise']:.1e} ({100.0 * ev['frac_points_above_1e-10']:.3f} % of points above 1e-10) "
+            f"pointwise by up to {ev['max_pointwise']:.1e} ({ev['frac_points_above_1e-10']:.1e} of the points above 1e-10) "
             "-- numerics_evidence; value_exact is the bit-identical flavour")
 
 
