@@ -338,6 +338,7 @@ def main():
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "cfg3b_solovev64k_rk4.in"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-entry", action="store_true", help="skip the host_entry leg (rays_hip_trace on host arrays)")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the two-streams leg (value_two_streams)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the trajectory gather (diagnostic)")
     ap.add_argument("--exchange", choices=("gather", "deposition"), default="gather",
                     help="what leaves the GPUs each pass: the packed trajectories, gathered to rank 0 "
@@ -563,6 +564,40 @@ def main():
         tr.launch(zero_fill=False)     # leave the arrays as the timed flavour wrote them
         torch.cuda.synchronize()
 
+    # ---- two independent passes in flight (one GPU; outside the timed region) ------------------------------------------
+    # One 64k fan is one ray per resident lane and the pass lasts as long as its longest ray: 55 % of the SIMD-time is
+    # idle (simd_idle_frac).  A host with INDEPENDENT fans to trace (a parameter scan, a time loop over launch conditions)
+    # can fill it: the same K passes issued alternately on two streams into two complete sets of result arrays, so that
+    # the blocks of pass i + 1 start on the CUs whose blocks of pass i have ended.  Reported next to `value`, never as it:
+    # `value` is K passes one after the other on one stream.
+    pipelined = None
+    if world == 1 and args.exchange == "gather" and not args.no_pipelined and 16.0 * (nv + 1) * npt * (hi - lo) <= 40e9:
+        tr2 = DeviceTrace(p, r0[lo:hi], n0[lo:hi], device=dev)
+        s_a, s_b = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(s_b):
+            tr2.launch(zero_fill=True)
+        torch.cuda.synchronize()
+        def both(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(n):
+                with torch.cuda.stream(s_a if k % 2 == 0 else s_b):
+                    (tr if k % 2 == 0 else tr2).launch(zero_fill=False)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        both(2)
+        el_p = both(args.steps)
+        same = bool(torch.equal(tr.npoints, tr2.npoints) and torch.equal(tr.ray_vec, tr2.ray_vec) and
+                    torch.equal(tr.residual, tr2.residual) and torch.equal(tr.stop_code, tr2.stop_code))
+        if not same:
+            raise SystemExit("bench.py: the two result sets of the two-stream passes differ")
+        pipelined = {"value_two_streams": total_steps / (el_p / args.steps), "ms_per_step_two_streams": 1e3 * el_p / args.steps,
+                     "two_streams_note": "the same K passes issued alternately on two HIP streams into two complete sets of result "
+                                         "arrays (identical, checked): what a host with independent fans gets out of the SIMD-time one "
+                                         "64k fan leaves idle (simd_idle_frac); `value` is K passes one after the other"}
+        del tr2
+        torch.cuda.empty_cache()
+
     if rank == 0 and gather is not None and args.verify_gather:
         # rank 0 re-traces every rank's block (block by block: the same kernel build each rank dispatched -- the
         # tolerance flavour's one-wave and two-waves builds are different compilations of the same arithmetic)
@@ -659,6 +694,8 @@ def main():
         line.update(split)
         if other is not None:
             line.update(other)
+        if pipelined is not None:
+            line.update(pipelined)
         host_bytes = 8.0 * (nv + 1) * (p.nstep_max + 1) * nray_total   # the caller's padded ray_results_m arrays
         if world == 1 and not args.no_host_entry and args.exchange == "gather" and host_bytes <= 8e9:
             try:   # outside the timed region: the rate the reference's own call site sees, both flavours
