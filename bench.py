@@ -122,28 +122,34 @@ def kernel_source_hash():
 def numerics_evidence(cfg_name, flavour):
     """What tests/test_gpu_numerics_full_fans.py MEASURED for this workload and flavour on the full fan (every recorded
     step restarted from the oracle's point; every traced point against the oracle's), replayed from
-    profiles/numerics_evidence.json when it was collected from the kernel sources this run is built from."""
-    path = os.path.join(ROOT, "profiles", "numerics_evidence.json")
-    if not os.path.exists(path):
-        return None
-    try:
-        e = json.load(open(path)).get(f"{cfg_name}::{flavour}")
-    except Exception as ex:
-        print(f"[bench] profiles/numerics_evidence.json unreadable: {ex}", file=sys.stderr)
-        return None
-    if not e:
-        return None
-    if e.get("source_hash") != kernel_source_hash():
-        print(f"[bench] profiles/numerics_evidence.json: {cfg_name}::{flavour} was measured on other kernel sources "
-              f"({e.get('source_hash')} != {kernel_source_hash()}): numerics_evidence omitted -- re-run "
-              "tests/test_gpu_numerics_full_fans.py on a GPU box and copy gpurun_out/numerics_evidence.json", file=sys.stderr)
-        return None
+    profiles/numerics_evidence.json -- or from gpurun_out/numerics_evidence.json, where that test leaves it on the box it
+    ran on -- when it was collected from the kernel sources this run is built from."""
     keys = ("steps_restarted", "n_above_1e-10", "n_above_1e-11", "max_per_step", "median_per_step", "points_compared",
             "max_pointwise", "frac_points_above_1e-10", "rays_surveyed", "rays_with_other_counts", "kernel")
-    out = {k: e.get(k) for k in keys}
-    out["source"] = ("replayed from profiles/numerics_evidence.json (tests/test_gpu_numerics_full_fans.py on MI355X, kernel "
-                     "sources hash " + str(e.get("source_hash")) + "); not measured in this run")
-    return out
+    stale = None
+    for rel in (("profiles", "numerics_evidence.json"), ("gpurun_out", "numerics_evidence.json")):
+        path = os.path.join(ROOT, *rel)
+        if not os.path.exists(path):
+            continue
+        try:
+            e = json.load(open(path)).get(f"{cfg_name}::{flavour}")
+        except Exception as ex:
+            print(f"[bench] {'/'.join(rel)} unreadable: {ex}", file=sys.stderr)
+            continue
+        if not e:
+            continue
+        if e.get("source_hash") != kernel_source_hash():
+            stale = ("/".join(rel), e.get("source_hash"))
+            continue
+        out = {k: e.get(k) for k in keys}
+        out["source"] = ("replayed from " + "/".join(rel) + " (tests/test_gpu_numerics_full_fans.py on MI355X, kernel "
+                         "sources hash " + str(e.get("source_hash")) + "); not measured in this run")
+        return out
+    if stale:
+        print(f"[bench] {stale[0]}: {cfg_name}::{flavour} was measured on other kernel sources ({stale[1]} != "
+              f"{kernel_source_hash()}): numerics_evidence omitted -- re-run tests/test_gpu_numerics_full_fans.py on a GPU box "
+              "and copy gpurun_out/numerics_evidence.json to profiles/", file=sys.stderr)
+    return None
 
 
 def numerics_text(flavour, is_tol_kernel, ev):

@@ -229,6 +229,7 @@ int get_axisym_device(rays::DevParams* D) {
     D->a_ne_grid = D->a_ne_fspl = D->a_te_grid = D->a_te_fspl = D->a_ti_grid = D->a_ti_fspl = nullptr;
     D->a_tab1d_doubles = 0;
     D->a_lds_tab = D->a_lds_rz = 0;
+    set_spline_axes(*D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     return 0;
   }
   const bool lin = D->a_mag_model == RAYS_AXI_MAG_EQDSK_LIN;
@@ -258,6 +259,12 @@ int get_axisym_device(rays::DevParams* D) {
   D->a_lin_dZ = g_axi.dZ;
   D->a_lds_tab = 0;
   D->a_lds_rz = 0;
+  {
+    const double* h = g_axi.blob.data();  // the host image of the same blob
+    const auto at = [&](int k, int n) { return n > 1 ? h + g_axi.off[k] : nullptr; };
+    set_spline_axes(*D, at(0, g_axi.nr), at(1, g_axi.nz), at(3, g_axi.n_rb), at(5, g_axi.n_ne), at(7, g_axi.n_te),
+                    at(9, g_axi.n_ti));
+  }
   return 0;
 }
 

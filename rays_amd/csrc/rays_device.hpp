@@ -71,6 +71,9 @@ struct DevParams {
   // likewise the two grids of the bicubic psi spline (r_grid then z_grid, 2 x ~65 doubles): the cell search reads
   // x(i-1), x(i) twice in a row, each a dependent trip to L2 otherwise
   unsigned a_lds_rz;
+  // the six spline grids (r, z, rb, ne, te, ti: kAxR ..): x(1), x(n) and RN(1 / (x(n) - x(1))), so that the uniform-grid
+  // estimate of the cell a point lies in needs no table access (rays_device_arith.inc: spl_guess; host: spline_axis)
+  double a_axis[6][3];
   double ds, s_max, omgrf, k0, clight, eps0, resid_limit;
   double omgrf2;               // omgrf**2                      equilibrium_m.f90:264
   double two_over_k0;          // 2./k0                         deriv_cold.f90:51

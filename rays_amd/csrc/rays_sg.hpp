@@ -51,6 +51,15 @@ enum : int {
   PC_F3 = 3      // corrector evaluation (:1142)
 };
 
+// Early exit of a predicated loop INSIDE divergent control flow: true while any of the lanes that are active there
+// still has work (the hardware's vote counts the active lanes only).  On the host emulator, where a vote is a rendezvous
+// of all 64 lanes, the loop just runs to its end (the predicates keep the arithmetic the same).
+#ifdef RAYS_HOST_EMUL
+#define RAYS_ANY_ACTIVE(x) true
+#else
+#define RAYS_ANY_ACTIVE(x) __any(x)
+#endif
+
 enum : unsigned { FL_START = 1u, FL_PHASE1 = 2u, FL_NORND = 4u, FL_STIFF = 8u, FL_FIRST = 16u };
 
 enum : int {
@@ -232,7 +241,7 @@ struct SgPhi {
     for (int l = 0; l < NV; l++) out[l] = 0.;
 #pragma unroll
     for (int q = 1; q <= R; q++) {
-      if (!__any(i == q)) continue;
+      if (!RAYS_ANY_ACTIVE(i == q)) continue;
       if (i == q) {
 #pragma unroll
         for (int l = 0; l < NV; l++) out[l] = lo[q - 1][l];
@@ -243,7 +252,7 @@ struct SgPhi {
   RAYS_DEV void set(int i, const double in[NV]) {  // phi(:, i) = in, i dynamic
 #pragma unroll
     for (int q = 1; q <= R; q++) {
-      if (!__any(i == q)) continue;
+      if (!RAYS_ANY_ACTIVE(i == q)) continue;
       if (i == q) {
 #pragma unroll
         for (int l = 0; l < NV; l++) lo[q - 1][l] = in[l];
@@ -257,7 +266,7 @@ struct SgPhi {
 #pragma unroll
     for (int q = 1; q <= R; q++) {
       const bool on = q >= a && q <= b;
-      if (!__any(on)) continue;
+      if (!RAYS_ANY_ACTIVE(on)) continue;
       if (on) {
         const double bq = beta(q);
 #pragma unroll
@@ -295,7 +304,7 @@ struct SgPhi {
 #pragma unroll
     for (int q = R; q >= 1; q--) {
       const bool on = q <= k;
-      if (!__any(on)) continue;
+      if (!RAYS_ANY_ACTIVE(on)) continue;
       if (on) {
         const double gg = g(q);
 #pragma unroll
@@ -319,7 +328,7 @@ struct SgPhi {
 #pragma unroll
     for (int q = 1; q <= R; q++) {
       const bool on = q <= k;
-      if (!__any(on)) continue;
+      if (!RAYS_ANY_ACTIVE(on)) continue;
       if (on) {
         const Recip b = make_recip(beta(q));
 #pragma unroll
@@ -344,7 +353,7 @@ struct SgPhi {
 #pragma unroll
     for (int q = 1; q <= R; q++) {
       const bool on = q <= k;
-      if (!__any(on)) continue;
+      if (!RAYS_ANY_ACTIVE(on)) continue;
       if (on) {
 #pragma unroll
         for (int l = 0; l < NV; l++) lo[q - 1][l] = lo[q - 1][l] + d[l];
@@ -371,7 +380,7 @@ struct SgPhi {
 #pragma unroll
     for (int q = R; q >= 1; q--) {
       const bool on = q <= ki;
-      if (!__any(on)) continue;
+      if (!RAYS_ANY_ACTIVE(on)) continue;
       if (on) {
         const double gg = g(q);
 #pragma unroll
@@ -982,7 +991,7 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
             if (ns <= 1) {
 #pragma unroll
               for (int iq = 1; iq <= 12; iq++) {
-                if (!__any(iq <= k)) break;
+                if (!RAYS_ANY_ACTIVE(iq <= k)) break;
                 if (iq <= k) {
                   const double c = 1.0 / (double)(iq * (iq + 1));
                   S.v(iq) = c;
@@ -1001,7 +1010,7 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
               const int lim = kp1 - ns;
 #pragma unroll
               for (int iq = 1; iq <= 12; iq++) {  // ascending: v(iq+1) is still the old value
-                if (!__any(iq <= lim)) break;
+                if (!RAYS_ANY_ACTIVE(iq <= lim)) break;
                 if (iq <= lim) {
                   const double c = S.v(iq) - a_ns * S.v(iq + 1);
                   S.v(iq) = c;
@@ -1015,7 +1024,7 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
               const int lim = kp2 - i;
 #pragma unroll
               for (int iq = 1; iq <= 12; iq++) {
-                if (!__any(iq <= lim)) break;
+                if (!RAYS_ANY_ACTIVE(iq <= lim)) break;
                 if (iq <= lim) w[iq] = w[iq] - a * w[iq + 1];
               }
               S.g(i) = w[1];

@@ -49,6 +49,8 @@ def _load(path):
     l.rays_emul_trace_group.restype = C.c_int
     l.rays_emul_trace_group.argtypes = [C.POINTER(RaysParams), C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, ip, ip, dp, dp, dp]
     l.rays_emul_trace_rk4_waves.restype = C.c_int
+    l.rays_emul_trace_sg_waves.restype = C.c_int
+    l.rays_emul_trace_sg_waves.argtypes = [C.POINTER(RaysParams), C.c_int, C.c_int, dp, dp, dp, dp, ip, ip, dp, dp, dp]
     l.rays_emul_trace_rk4_waves.argtypes = [C.POINTER(RaysParams), C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, ip, ip, dp, dp, dp]
     l.rays_emul_set_zfun_table.restype = C.c_int
     l.rays_emul_set_zfun_table.argtypes = [dp, C.c_int, C.c_double, C.c_double]
@@ -125,4 +127,24 @@ def trace_rk4_waves(p: RaysParams, rvec0, rindex_vec0, nwaves: int = 1, library=
                                                       d(out["max_residuals"]))
     if rc:
         raise RuntimeError(f"rays_emul_trace_rk4_waves rc={rc}")
+    return out
+
+
+def trace_sg_waves(p: RaysParams, rvec0, rindex_vec0, nwaves: int = 1, library=None) -> dict:
+    """The one-ray-per-lane Shampine-Gordon kernel on `nwaves` whole 64-lane waves (rays beyond 64 * nwaves are pulled
+    by lanes whose ray has ended)."""
+    rvec0 = np.ascontiguousarray(rvec0, dtype=np.float64)
+    rindex_vec0 = np.ascontiguousarray(rindex_vec0, dtype=np.float64)
+    nray, nv, npt = len(rvec0), p.nv, p.nstep_max + 1
+    out = dict(ray_vec=np.zeros((nray, npt, nv)), residual=np.zeros((nray, npt)),
+               npoints=np.zeros(nray, dtype=np.int32), stop_code=np.zeros(nray, dtype=np.int32),
+               end_ray_vec=np.zeros((nray, nv)), end_residuals=np.zeros(nray), max_residuals=np.zeros(nray))
+    d = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    rc = (library or lib()).rays_emul_trace_sg_waves(C.byref(p), int(nwaves), nray, d(rvec0), d(rindex_vec0),
+                                                     d(out["ray_vec"]), d(out["residual"]), i(out["npoints"]),
+                                                     i(out["stop_code"]), d(out["end_ray_vec"]), d(out["end_residuals"]),
+                                                     d(out["max_residuals"]))
+    if rc:
+        raise RuntimeError(f"rays_emul_trace_sg_waves rc={rc}")
     return out

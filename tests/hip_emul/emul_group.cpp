@@ -16,6 +16,7 @@ static int attach_axisym_tables(const rays_params_t* p, rays::DevParams& D) {
   D.a_r_grid = g_axi[0].data(); D.a_z_grid = g_axi[1].data(); D.a_psi_fspl = g_axi[2].data();
   D.a_rb_grid = g_axi[3].data(); D.a_rb_fspl = g_axi[4].data(); D.a_ne_grid = g_axi[5].data(); D.a_ne_fspl = g_axi[6].data();
   D.a_te_grid = g_axi[7].data(); D.a_te_fspl = g_axi[8].data(); D.a_ti_grid = g_axi[9].data(); D.a_ti_fspl = g_axi[10].data();
+  set_spline_axes(D, D.a_r_grid, D.a_z_grid, D.a_rb_grid, D.a_ne_grid, D.a_te_grid, D.a_ti_grid);
   return 0;
 }
 
@@ -113,5 +114,43 @@ extern "C" int rays_emul_trace_rk4_waves(const rays_params_t* p, int nwaves, int
   RAYS_RK4W_CASE(0, 2, 7) RAYS_RK4W_CASE(4, 2, 7) RAYS_RK4W_CASE(1, 2, 7) RAYS_RK4W_CASE(5, 2, 7)
   RAYS_RK4W_CASE(2, 2, 8) RAYS_RK4W_CASE(6, 2, 8)
 #undef RAYS_RK4W_CASE
+  return 4;
+}
+
+// The one-ray-per-lane Shampine-Gordon kernel (rays_sg.hpp: sg_trace_kernel) on `nwaves` blocks of one whole wave: the
+// phase / interval votes with 64 lanes, rays that end on different trips, lanes that pull the next ray in index order.
+template <int EQ, int NS, int NV>
+static int run_sg_waves(const rays::DevParams& D, const rays::TraceArgs& A, int nwaves) {
+  gridDim.x = (unsigned)nwaves;
+  blockDim.x = 64;
+  std::vector<double> far((size_t)rays::sg_far_doubles_per_lane<NV>() * 64 * (size_t)nwaves, 0.0);
+  rays::TraceArgs A2 = A;
+  A2.sg_far = far.data();
+  A2.sg_far_lanes = 64ll * nwaves;
+  for (int b = 0; b < nwaves; b++) {
+    blockIdx.x = (unsigned)b;
+    wave_emul::run_wave(0u, [&] { rays::sg_trace_kernel<EQ, NS, 0, NV>(D, A2); }, threadIdx);
+  }
+  return 0;
+}
+extern "C" int rays_emul_trace_sg_waves(const rays_params_t* p, int nwaves, int nray, const double* rvec0,
+                                        const double* rindex_vec0, double* ray_vec, double* residual, int32_t* npoints,
+                                        int32_t* stop_code, double* end_ray_vec, double* end_residuals, double* max_residuals) {
+  if (p->ode_solver != RAYS_ODE_SG || p->ray_deriv != RAYS_DERIV_COLD || p->multi_spec_damping || nwaves < 1) return 1;
+  unsigned counter = 0;
+  rays::TraceArgs A = rays::TraceArgs();
+  A.nray = nray; A.rvec0 = rvec0; A.rindex_vec0 = rindex_vec0; A.ray_vec = ray_vec;
+  A.residual = residual; A.npoints = npoints; A.stop_code = stop_code; A.end_ray_vec = end_ray_vec;
+  A.end_residuals = end_residuals; A.max_residuals = max_residuals; A.next_ray = &counter;
+  rays::DevParams D = make_dev_params(*p);
+  if (int rc = attach_axisym_tables(p, D)) return rc;
+  if (p->damping_model) {
+    if (g_zfun.empty()) return 2;
+    D.zf_fspl = g_zfun.data(); D.zf_nx = g_zf_nx; D.zf_xmin = g_zf_xmin; D.zf_xmax = g_zf_xmax;
+  }
+  const int e = p->equilib_model | (unit_exponents(*p) ? rays::kEqUnitExp : 0), ns = p->nspec + 1, nv = p->nv;
+#define RAYS_SGW_CASE(E, N, V) if (e == E && ns == N && nv == V) return run_sg_waves<E, N, V>(D, A, nwaves);
+  RAYS_SGW_CASE(1, 2, 7) RAYS_SGW_CASE(5, 2, 7) RAYS_SGW_CASE(2, 2, 8) RAYS_SGW_CASE(6, 2, 8)
+#undef RAYS_SGW_CASE
   return 4;
 }

@@ -130,6 +130,7 @@ extern "C" int rays_emul_trace_ex(const rays_params_t* p, int nray, const double
     D.a_r_grid = g_axi[0].data(); D.a_z_grid = g_axi[1].data(); D.a_psi_fspl = g_axi[2].data();
     D.a_rb_grid = g_axi[3].data(); D.a_rb_fspl = g_axi[4].data(); D.a_ne_grid = g_axi[5].data(); D.a_ne_fspl = g_axi[6].data();
     D.a_te_grid = g_axi[7].data(); D.a_te_fspl = g_axi[8].data(); D.a_ti_grid = g_axi[9].data(); D.a_ti_fspl = g_axi[10].data();
+    set_spline_axes(D, D.a_r_grid, D.a_z_grid, D.a_rb_grid, D.a_ne_grid, D.a_te_grid, D.a_ti_grid);
   }
   // same kernel selection as rays_capi.hip: find_kernel (EQ = model | kEqUnitExp)
   const int e = p->equilib_model | (unit_exponents(*p) ? rays::kEqUnitExp : 0), d = p->ray_deriv, s = p->ode_solver;
@@ -179,6 +180,7 @@ extern "C" int rays_emul_ray_init(const rays_params_t* p, const rays_fan_t* fan,
     D.a_r_grid = g_axi[0].data(); D.a_z_grid = g_axi[1].data(); D.a_psi_fspl = g_axi[2].data();
     D.a_rb_grid = g_axi[3].data(); D.a_rb_fspl = g_axi[4].data(); D.a_ne_grid = g_axi[5].data(); D.a_ne_fspl = g_axi[6].data();
     D.a_te_grid = g_axi[7].data(); D.a_te_fspl = g_axi[8].data(); D.a_ti_grid = g_axi[9].data(); D.a_ti_fspl = g_axi[10].data();
+    set_spline_axes(D, D.a_r_grid, D.a_z_grid, D.a_rb_grid, D.a_ne_grid, D.a_te_grid, D.a_ti_grid);
   }
   int count = 0;
   for (int il = 0; il < F.n_launch; il++)
@@ -209,6 +211,7 @@ extern "C" int rays_emul_deposition(const rays_params_t* p, int which, int n_bin
     D.a_nr = g_axi_n[0]; D.a_nz = g_axi_n[1]; D.a_n_rb = g_axi_n[2];
     D.a_r_grid = g_axi[0].data(); D.a_z_grid = g_axi[1].data(); D.a_psi_fspl = g_axi[2].data();
     D.a_rb_grid = g_axi[3].data(); D.a_rb_fspl = g_axi[4].data();
+    set_spline_axes(D, D.a_r_grid, D.a_z_grid, D.a_rb_grid, nullptr, nullptr, nullptr);
   }
   rays::DepArgs A;
   A.which = which; A.n_bins = n_bins; A.nray = nray; A.nv = p->nv; A.npt = p->nstep_max + 1;
