@@ -160,7 +160,8 @@ def numerics_text(flavour, is_tol_kernel, ev):
             "step indices / stop flags exactly the reference's")
     if ev is None:
         return base + "; per-step and pointwise deviation of this build not measured (see value_exact for the bit-exact flavour)"
-    return (base + f" on all {ev['rays_surveyed']} rays surveyed; restarted from every one of the oracle's {ev['steps_restarted']} "
+    where = " (one-GPU fan of this workload)" if ev.get("fan") else ""
+    return (base + f" on all {ev['rays_surveyed']} rays surveyed{where}; restarted from every one of the oracle's {ev['steps_restarted']} "
             f"recorded points, {ev['n_above_1e-10']} steps land further than 1e-10 (relative, norm-wise on r and k) from the "
             f"reference's next point, max {ev['max_per_step']:.2e}; accumulated along the rays the traced fan deviates "
             f"pointwise by up to {ev['max_pointwise']:.1e} ({ev['frac_points_above_1e-10']:.1e} of the points above 1e-10) "
@@ -660,8 +661,11 @@ def main():
         idle = simd_idle_fraction(tr.npoints.cpu().numpy()) if world == 1 else None
         is_tol_kernel = "<" in kname and bool(int(kname.split("<")[1].split(",")[0]) & 16)
         evidence = None
-        if args.fan_scale == 1 and args.nstep_max is None and world == 1:
+        if args.fan_scale == 1 and args.nstep_max is None:
             evidence = numerics_evidence(os.path.basename(args.config), "tolerance" if is_tol_kernel else "exact")
+            if evidence is not None and world > 1:
+                evidence["fan"] = ("measured on the one-GPU fan of this workload; the N-GPU fan is the same fan widened in "
+                                   "n_theta (weak scaling), traced by the same kernel")
         line = {
             "metric": metric_name(p, hi - lo),
             "value": value, "unit": "ray-steps/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps,
