@@ -125,7 +125,7 @@ def numerics_evidence(cfg_name, flavour):
     profiles/numerics_evidence.json -- or from gpurun_out/numerics_evidence.json, where that test leaves it on the box it
     ran on -- when it was collected from the kernel sources this run is built from."""
     keys = ("steps_restarted", "n_above_1e-10", "n_above_1e-11", "max_per_step", "median_per_step", "points_compared",
-            "max_pointwise", "frac_points_above_1e-10", "rays_surveyed", "rays_with_other_counts", "kernel")
+            "points_not_identical", "max_pointwise", "frac_points_above_1e-10", "rays_surveyed", "rays_with_other_counts", "kernel")
     stale = None
     for rel in (("profiles", "numerics_evidence.json"), ("gpurun_out", "numerics_evidence.json")):
         path = os.path.join(ROOT, *rel)

@@ -31,10 +31,12 @@ def _rel(a, b, sl):
     return out
 
 
-def survey(p, r0, n0, ray_stride=1, chunk_rays=4096, restart_batch=65536, n_worst=8, progress=None):
+def survey(p, r0, n0, ray_stride=1, chunk_rays=4096, restart_batch=65536, n_worst=8, progress=None, per_step=True):
     """Returns a dict of plain numbers (JSON-ready).  `restart_batch`: states per `ode_step` call -- below two waves per
     SIMD worth of states the one-wave-per-SIMD build of the kernel serves the call, from 131072 on the two-waves build:
-    pick the one the fan itself dispatches (`hip.kernel_name(p, len(r0))`)."""
+    pick the one the fan itself dispatches (`hip.kernel_name(p, len(r0))`).  per_step=False: the pointwise comparison and
+    the counts only (Shampine-Gordon fans: an output step there is a whole restarted integration whose tolerances the ray
+    carries along, so a restart from a recorded point is not the reference's next step)."""
     import torch
     from rays_amd.trace import DeviceTrace
 
@@ -48,7 +50,7 @@ def survey(p, r0, n0, ray_stride=1, chunk_rays=4096, restart_batch=65536, n_wors
     d_npts, d_codes = tr.npoints.cpu().numpy(), tr.stop_code.cpu().numpy()
     ds = float(p.ds)
     st = dict(steps_restarted=0, restarts_stopped=0, max_per_step=0.0, max_per_step_r=0.0, max_per_step_k=0.0,
-              points_compared=0, max_pointwise=0.0, rays_with_other_counts=0, rays_surveyed=int(len(sel)))
+              points_compared=0, points_not_identical=0, max_pointwise=0.0, rays_with_other_counts=0, rays_surveyed=int(len(sel)))
     n_step_above = {t: 0 for t in THRESHOLDS}
     n_point_above = {t: 0 for t in THRESHOLDS}
     worst = []   # (err, ray, point, npoints)
@@ -67,11 +69,16 @@ def survey(p, r0, n0, ray_stride=1, chunk_rays=4096, restart_batch=65536, n_wors
         g2, r2 = got[live], ref[live]
         pe = np.maximum(_rel(g2, r2, slice(0, 3)), _rel(g2, r2, slice(3, 6)))
         st["points_compared"] += int(len(pe))
+        st["points_not_identical"] += int(((g2 != r2) & ~(np.isnan(g2) & np.isnan(r2))).any(axis=-1).sum())  # all nv components
         if len(pe):
             st["max_pointwise"] = max(st["max_pointwise"], float(pe.max()))
             for t in THRESHOLDS:
                 n_point_above[t] += int((pe > t).sum())
         del got, g2, r2
+        if not per_step:
+            if progress:
+                progress(f"  rays {rays[0]}..{rays[-1]}: {st['points_compared']} points so far, max pointwise {st['max_pointwise']:.3e}")
+            continue
         # ---- per step: one-step restarts from every oracle point ----
         has = npts >= 2
         cnt = np.where(has, npts - 1, 0)

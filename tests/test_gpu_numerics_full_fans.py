@@ -7,8 +7,8 @@ oracle (tests/numerics_survey.py) -- not on 30 rays of a fixture:
 
 For the tolerance flavour the test records and bounds: steps above 1e-10 / 1e-11 (north_star's per-step bar), the
 largest per-step error, the largest POINTWISE deviation of the traced fan from the oracle and the share of points
-above 1e-10; ray counts and stop codes of every surveyed ray must be the oracle's.  For the exact flavour everything must
-be zero.  The numbers go to gpurun_out/numerics_evidence.json (copied to profiles/numerics_evidence.json, which
+above 1e-10; ray counts and stop codes of every surveyed ray must be the oracle's.  For the exact flavour (headline fan and cfg 5b) everything
+must be zero.  The numbers go to gpurun_out/numerics_evidence.json (copied to profiles/numerics_evidence.json, which
 bench.py quotes in its line as `numerics_evidence`, labelled as replayed and keyed by the kernel sources' hash)."""
 import json
 import os
@@ -77,9 +77,10 @@ def test_tolerance_flavour_on_the_full_fan(cfg, stride, batch):
     assert res["max_pointwise"] <= b["max_pointwise"]
 
 
-@pytest.mark.parametrize("cfg,stride,batch", [FANS[0]])
-def test_exact_flavour_on_the_full_headline_fan(cfg, stride, batch):
-    """The exact kernel on the same survey: every restarted step and every traced point IS the oracle's."""
+@pytest.mark.parametrize("cfg,stride,batch", FANS[:2])
+def test_exact_flavour_on_the_full_fans(cfg, stride, batch):
+    """The exact kernels on the same survey (headline fan; the eqdsk fan, whose spline cell search takes its estimate from
+    host-computed grid constants): every restarted step and every traced point IS the oracle's."""
     prev = hip.set_numerics("exact")
     try:
         p, r0, n0 = _fan(cfg)
@@ -88,4 +89,31 @@ def test_exact_flavour_on_the_full_headline_fan(cfg, stride, batch):
         hip.set_numerics(prev)
     _record(cfg, "exact", res)
     assert res["rays_with_other_counts"] == 0 and res["restarts_stopped"] == 0
-    assert res["max_per_step"] == 0.0 and res["max_pointwise"] == 0.0
+    assert res["max_per_step"] == 0.0 and res["max_pointwise"] == 0.0 and res["points_not_identical"] == 0
+
+
+def test_shampine_gordon_eqdsk_fan_is_the_oracles_at_full_size():
+    """BASELINE config 5 (eqdsk splines + damping, SG, 262 144 rays) at full size: every recorded point of every ray, the
+    counts and the stop codes are the oracle's, bit for bit (the kernel has one numerics flavour; the oracle's share of
+    the test is ~20 s of the box's host cores)."""
+    cfg = "cfg5_axisym256k_sg_damp.in"
+    p, r0, n0 = _fan(cfg)
+    assert hip.kernel_name(p, len(r0)).startswith("sg_trace_kernel<6, 2, 0, 8>")
+    res = survey(p, r0, n0, per_step=False, progress=print)
+    _record(cfg, "exact", res)
+    assert res["rays_surveyed"] == len(r0) and res["rays_with_other_counts"] == 0
+    assert res["points_compared"] > 7_000_000 and res["max_pointwise"] == 0.0 and res["points_not_identical"] == 0
+
+
+def test_shampine_gordon_finite_difference_fan_is_the_oracles_at_full_size():
+    """BASELINE config 3 (Solovev 64k fan, SG + finite-difference dD: `sg_group_kernel`, one ray per group of four lanes)
+    launched at full size: every recorded point of every FOURTH ray (16 384 rays; with fourteen determinants per
+    evaluation the oracle's share is ~30 s of the box's host cores: 64 s for every second ray, same result), the counts
+    and the stop codes are the oracle's, bit for bit."""
+    cfg = "cfg3_solovev64k_sg_num.in"
+    p, r0, n0 = _fan(cfg)
+    assert hip.kernel_name(p, len(r0)).startswith("sg_group_kernel<5, 2, 4>")
+    res = survey(p, r0, n0, ray_stride=4, per_step=False, progress=print)
+    _record(cfg, "exact", res)
+    assert res["rays_surveyed"] == len(r0) // 4 and res["rays_with_other_counts"] == 0
+    assert res["points_compared"] > 3_000_000 and res["max_pointwise"] == 0.0 and res["points_not_identical"] == 0
