@@ -969,19 +969,17 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
           if (ns <= kold) ns = ns + 1;
           const int nsp1 = ns + 1;
           if (ns <= k) {
+            // Order of this block: the reference runs (1) the recurrence psi -> beta -> alpha -> sig for i = ns+1..k, (2) the
+            // v / w block, (3) g(i) for i = ns+2..k+1 from alpha(i-1) and w.  (2) reads nothing (1) writes (alpha(2..ns-1),
+            // alpha(ns) = 1/ns, v), and pass i of (3) needs exactly the alpha pass i-1 of (1) has produced, over the same
+            // range: here (2) comes first and (1), (3) are ONE loop.  beta(i-1), psi(i-1), sig(i), alpha(i) of the
+            // recurrences are the values just computed, carried in registers -- a pass waits for one read of its
+            // storage (the old psi(i-1)) instead of five dependent ones.  Every operation and its order are unchanged.
+            const double alpha_ns = 1.0 / (double)ns;
             S.beta(ns) = 1.0;
-            S.alpha(ns) = 1.0 / (double)ns;
+            S.alpha(ns) = alpha_ns;
             double temp1 = h * (double)ns;
             S.sig(nsp1) = 1.0;
-            for (int i = nsp1; i <= k; i++) {
-              const double temp2 = S.psi(i - 1);
-              S.psi(i - 1) = temp1;
-              S.beta(i) = S.beta(i - 1) * S.psi(i - 1) / temp2;
-              temp1 = temp2 + h;
-              S.alpha(i) = h / temp1;
-              S.sig(i + 1) = (double)i * S.alpha(i) * S.sig(i);
-            }
-            S.psi(k) = temp1;
             // w(1:12) is a work vector of this block only (ode_RAYS.f90:946-986): kept in registers,
             // loops unrolled over the maximum order with per-lane bounds as predicates and a
             // wave-uniform early exit.
@@ -1006,29 +1004,41 @@ sg_trace_kernel(const DevParams P_kernarg, const TraceArgs A_hot) {
                   S.v(i) = S.v(i) - S.alpha(j + 1) * S.v(i + 1);
                 }
               }
-              const double a_ns = S.alpha(ns);
               const int lim = kp1 - ns;
+              double v_cur = S.v(1);
 #pragma unroll
               for (int iq = 1; iq <= 12; iq++) {  // ascending: v(iq+1) is still the old value
                 if (!RAYS_ANY_ACTIVE(iq <= lim)) break;
                 if (iq <= lim) {
-                  const double c = S.v(iq) - a_ns * S.v(iq + 1);
+                  const double v_nxt = S.v(iq + 1);
+                  const double c = v_cur - alpha_ns * v_nxt;
                   S.v(iq) = c;
                   w[iq] = c;
+                  v_cur = v_nxt;
                 }
               }
               S.g(nsp1) = w[1];
             }
-            for (int i = ns + 2; i <= kp1; i++) {
-              const double a = S.alpha(i - 1);
-              const int lim = kp2 - i;
+            double beta_c = 1.0, sig_c = 1.0;
+            for (int i = nsp1; i <= k; i++) {
+              const double temp2 = S.psi(i - 1);
+              S.psi(i - 1) = temp1;
+              beta_c = beta_c * temp1 / temp2;  // beta(i) = beta(i-1)*psi(i-1)/temp2
+              S.beta(i) = beta_c;
+              temp1 = temp2 + h;
+              const double alpha_i = h / temp1;
+              S.alpha(i) = alpha_i;
+              sig_c = (double)i * alpha_i * sig_c;  // sig(i+1) = i*alpha(i)*sig(i)
+              S.sig(i + 1) = sig_c;
+              const int lim = kp1 - i;  // g(i+1): w(iq) = w(iq) - alpha(i)*w(iq+1), iq = 1..kp2-(i+1)
 #pragma unroll
               for (int iq = 1; iq <= 12; iq++) {
                 if (!RAYS_ANY_ACTIVE(iq <= lim)) break;
-                if (iq <= lim) w[iq] = w[iq] - a * w[iq + 1];
+                if (iq <= lim) w[iq] = w[iq] - alpha_i * w[iq + 1];
               }
-              S.g(i) = w[1];
+              S.g(i + 1) = w[1];
             }
+            S.psi(k) = temp1;
           }
           SG_PROF(12);  // coefficient block
           F.scale(nsp1, k, [&](int i) { return S.beta(i); });

@@ -1142,19 +1142,13 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
       if (ns <= kold) ns = ns + 1;
       const int nsp1 = ns + 1;
       if (ns <= k) {
+        // (order and register carries as in rays_sg.hpp: the v / w block first, then the recurrence psi -> beta -> alpha
+        //  -> sig and g(i+1) from alpha(i) as ONE loop; every operation and its order are the reference's)
+        const double alpha_ns = 1.0 / (double)ns;
         S.beta(ns) = 1.0;
-        S.alpha(ns) = 1.0 / (double)ns;
+        S.alpha(ns) = alpha_ns;
         double temp1 = h * (double)ns;
         S.sig(nsp1) = 1.0;
-        for (int i = nsp1; i <= k; i++) {
-          const double temp2 = S.psi(i - 1);
-          S.psi(i - 1) = temp1;
-          S.beta(i) = S.beta(i - 1) * S.psi(i - 1) / temp2;
-          temp1 = temp2 + h;
-          S.alpha(i) = h / temp1;
-          S.sig(i + 1) = (double)i * S.alpha(i) * S.sig(i);
-        }
-        S.psi(k) = temp1;
         double w[14];
 #pragma unroll
         for (int iq = 0; iq < 14; iq++) w[iq] = 0.;
@@ -1176,29 +1170,41 @@ void sg_group_kernel(const DevParams P_kernarg, const TraceArgs A_hot)
               S.v(i) = S.v(i) - S.alpha(j + 1) * S.v(i + 1);
             }
           }
-          const double a_ns = S.alpha(ns);
           const int lim = kp1 - ns;
+          double v_cur = S.v(1);
 #pragma unroll
           for (int iq = 1; iq <= 12; iq++) {  // ascending: v(iq+1) is still the old value
             if (iq > kcap) continue;
             if (iq <= lim) {
-              const double cq = S.v(iq) - a_ns * S.v(iq + 1);
+              const double v_nxt = S.v(iq + 1);
+              const double cq = v_cur - alpha_ns * v_nxt;
               S.v(iq) = cq;
               w[iq] = cq;
+              v_cur = v_nxt;
             }
           }
           S.g(nsp1) = w[1];
         }
-        for (int i = ns + 2; i <= kp1; i++) {
-          const double a = S.alpha(i - 1);
-          const int lim = kp2 - i;
+        double beta_c = 1.0, sig_c = 1.0;
+        for (int i = nsp1; i <= k; i++) {
+          const double temp2 = S.psi(i - 1);
+          S.psi(i - 1) = temp1;
+          beta_c = beta_c * temp1 / temp2;  // beta(i) = beta(i-1)*psi(i-1)/temp2
+          S.beta(i) = beta_c;
+          temp1 = temp2 + h;
+          const double alpha_i = h / temp1;
+          S.alpha(i) = alpha_i;
+          sig_c = (double)i * alpha_i * sig_c;  // sig(i+1) = i*alpha(i)*sig(i)
+          S.sig(i + 1) = sig_c;
+          const int lim = kp1 - i;  // g(i+1): w(iq) = w(iq) - alpha(i)*w(iq+1), iq = 1..kp2-(i+1)
 #pragma unroll
           for (int iq = 1; iq <= 12; iq++) {
             if (iq > kcap) continue;
-            if (iq <= lim) w[iq] = w[iq] - a * w[iq + 1];
+            if (iq <= lim) w[iq] = w[iq] - alpha_i * w[iq + 1];
           }
-          S.g(i) = w[1];
+          S.g(i + 1) = w[1];
         }
+        S.psi(k) = temp1;
       }
       SG_PROF(12);  // coefficient block
       F.scale(nsp1, k, S, ncap, any_hi);
