@@ -26,5 +26,9 @@ except Exception as e:
     print("$t: no summary:", e)
 PY
 done | tee $O/profile_overview.txt
+# the line to be tracked: once more, now that this session's counters and numerics evidence exist (in this scratch copy of the
+# repo), so that its roofline.traffic / roofline_fp64 / numerics_evidence are the ones of these sources
+python tools/update_counters.py gpurun_out/prof_*/pmc_summary.json > /dev/null 2>&1; cp gpurun_out/numerics_evidence.json profiles/numerics_evidence.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err; head -c 200 $O/bench_n1.json; echo
 [ -n "$REHEARSE" ] && ( bash tools/rehearse_multi_gpu.sh > $O/rehearse.log 2>&1; cp gpurun_out/rehearse/rehearse_n*.txt $O/ 2>/dev/null; tail -2 $O/rehearse.log )
 python tools/kernel_resources_all.py > $O/kernel_resources.txt 2> $O/kernel_resources.err; tail -3 $O/kernel_resources.txt
