@@ -255,6 +255,7 @@ int get_axisym_device(rays::DevParams* D) {
   D->a_te_grid = b + g_axi.off[7]; D->a_te_fspl = b + g_axi.off[8];
   D->a_ti_grid = b + g_axi.off[9]; D->a_ti_fspl = b + g_axi.off[10];
   D->a_tab1d_doubles = (int)(g_axi.blob.size() - g_axi.off[3]);  // rb .. ti: contiguous at the end of the blob
+  for (int k = 0; k < 8; k++) D->a_tab_off[k] = (int)(g_axi.off[3 + k] - g_axi.off[3]);
   D->a_lin_dR = g_axi.dR;
   D->a_lin_dZ = g_axi.dZ;
   D->a_lds_tab = 0;

@@ -74,6 +74,10 @@ struct DevParams {
   // the six spline grids (r, z, rb, ne, te, ti: kAxR ..): x(1), x(n) and RN(1 / (x(n) - x(1))), so that the uniform-grid
   // estimate of the cell a point lies in needs no table access (rays_device_arith.inc: spl_guess; host: spline_axis)
   double a_axis[6][3];
+  int a_tab_off[8];         // offsets (doubles) of rb_grid, rb_fspl, ne_grid, ne_fspl, te_grid, te_fspl, ti_grid, ti_fspl within the
+                            // contiguous block of 1-D tables (a_rb_grid ..): what the staged LDS copy is indexed with
+  int a_profiles_one_grid;  // 1: Te(psi) and Ti(psi) are tabulated on ONE grid (same length, same values), 2: n(psi) as well:
+                            // one cell search serves the lookups that share a grid (host: set_spline_axes)
   double ds, s_max, omgrf, k0, clight, eps0, resid_limit;
   double omgrf2;               // omgrf**2                      equilibrium_m.f90:264
   double two_over_k0;          // 2./k0                         deriv_cold.f90:51

@@ -11,4 +11,4 @@ for rep in 1 2; do
   python tools/variant_time_cfg.py configs/cfg5_axisym256k_sg_damp.in exact 3 >> $out
 done
 cat $out
-python -m pytest tests -m gpu -x -q -k "axisym or eqdsk or cfg5 or deposition or ray_init or golden or parity" 2>&1 | tail -4
+python -m pytest tests -m gpu -x -q -k "axisym or eqdsk or cfg5 or deposition or ray_init or golden or parity or profile" 2>&1 | tail -4
