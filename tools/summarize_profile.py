@@ -43,6 +43,8 @@ if m("SQ_INSTS_VALU") and m("SQ_WAVES"):
     if f64:
         d["f64_arith_fraction_of_valu"] = f64 / m("SQ_INSTS_VALU")
 if m("SQ_WAVE_CYCLES") and m("SQ_WAIT_ANY"):
+    # SQ_WAIT_ANY: wave-cycles waiting for anything (memory counters, but also issue and dependencies): an upper bound on
+    # memory waits -- the headline kernel, whose trip holds no s_waitcnt, shows 0.20 (profiles/README.md)
     d["wave_time_parked_in_waitcnt"] = m("SQ_WAIT_ANY") / m("SQ_WAVE_CYCLES")
 if m("GRBM_GUI_ACTIVE") and stats:
     d["effective_clock_GHz"] = m("GRBM_GUI_ACTIVE") / 8.0 / stats["avg_ns"]  # summed over 8 XCDs
