@@ -45,3 +45,42 @@ def test_profile_lookups_whatever_grids_they_share(mode, fixture):
     finally:
         hip.set_numerics(prev)
         load_golden(fixture)   # the fixture's own tables back into the libraries
+
+
+def test_spline_lookups_on_and_beside_the_grid_lines():
+    """States whose R or Z sits ON a grid line of the psi spline or one ulp beside it -- where the cell estimate of the one-trip
+    search (rays_device_arith.inc: spl_guess) can be a cell off and the lookup settles and fetches again -- through the device
+    RHS probe against the oracle's, bit for bit (dD/dx, dD/dk, dD/dw, dv/ds, residual, codes)."""
+    from rays_amd.params import copy_params
+    g, nml, p = load_golden("gold_axisym64_eqdsk129_tspline_damp_rk4")
+    tab = _tables(g)
+    q = copy_params(p)          # the probe kernel evaluates the nv = 7 rows
+    q.nv, q.damping_model = 7, 0
+    base = np.array(g["ray_vec"][0, 3, :7], dtype=np.float64)   # a state inside the plasma
+    r_axis, z_axis = float(np.hypot(base[0], base[1])), float(base[2])
+    states = []
+    for grid, which in ((tab["r_grid"], 0), (tab["z_grid"], 2)):
+        inner = np.asarray(grid[2:-2], dtype=np.float64)
+        for x in np.concatenate([inner, np.nextafter(inner, -np.inf), np.nextafter(inner, np.inf)]):
+            v = base.copy()
+            if which == 0:
+                v[0], v[1] = x, 0.0        # R = |x| exactly
+                v[2] = z_axis
+            else:
+                v[0], v[1] = r_axis, 0.0
+                v[2] = x
+            states.append(v)
+    v = np.array(states)
+    dev = hip.probe(q, v)
+    n_inside = 0
+    for i in range(len(v)):
+        ora = oracle_lib.probe(q, v[i])
+        np.testing.assert_array_equal(dev["codes"][i], ora["codes"], err_msg=f"codes of state {i}: {v[i][:3]}")
+        if ora["codes"][0] != 0:
+            continue   # the equilibrium refuses the point (outside the plasma / box): the fields are undefined in the reference
+        n_inside += 1
+        for key in ("cold", "dvds"):
+            np.testing.assert_array_equal(dev[key][i], ora[key][:7] if key == "cold" else ora[key],
+                                          err_msg=f"{key} of state {i}: {v[i][:3]}")
+        np.testing.assert_array_equal(dev["resid"][i], ora["resid"])
+    assert n_inside > 100   # most of these points lie inside the plasma: the lookups were really made
